@@ -1,0 +1,179 @@
+/*
+ * grafthip.h -- C ABI of libgrafthip.so: the per-pixel path of the ray tracer (ray generation, closest hit
+ * over spheres and planes, shadow rays, diffuse + ambient shading, mirror-reflection chain) as hand-written
+ * HIP kernels for AMD Instinct MI355X (gfx950).
+ *
+ * The library replaces the body of `void launchRays(void)` (reference mainTracing.c:387-443) and everything
+ * it calls (mainTracing.c:104-372, shapes.c:38-101, vector.c:18-82).  The reference reads its inputs from
+ * file-scope globals (mainTracing.c:29-67); here they travel in three plain structs.  The reference hands
+ * its result to pixSetRGB(x, y, r, g, b) once per pixel (mainTracing.c:422, :439; 000pixel.h:55); here the
+ * caller receives a frame indexed by the LOOP indices (iy, ix) of mainTracing.c:392-393 and feeds pixSetRGB
+ * from it (raytracing_amd/csrc/launch_rays_dropin.c shows that loop).
+ *
+ * Conventions: every function returns GRAFT_OK (0) or a GRAFT_ERR_* code (the only convention the
+ * reference documents is "0 if no error", 000pixel.h:30); graftLastError() describes the last failure on
+ * the calling thread's process.  One process drives one GPU; the library is not re-entrant (neither is the
+ * reference: launchRays is only ever called from the one event-loop thread, mainTracing.c:630, :642).
+ * All arithmetic on the path is IEEE double in the reference's operation order.
+ */
+#ifndef GRAFTHIP_H
+#define GRAFTHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRAFT_API __attribute__((visibility("default")))
+
+enum { GRAFT_OK = 0, GRAFT_ERR_ARG = 1, GRAFT_ERR_UNSUPPORTED = 2, GRAFT_ERR_HIP = 3, GRAFT_ERR_STATE = 4 };
+
+enum { GRAFT_SPHERE = 0, GRAFT_PLANE = 1 };             /* shape.intersection == sphereIntersect | planeIntersect */
+enum { GRAFT_ORTHOGRAPHIC = 0, GRAFT_PERSPECTIVE = 1 }; /* mainTracing.c:23-24 */
+enum { GRAFT_ANTIALIASING_OFF = 0, GRAFT_ANTIALIASING_ON = 1 }; /* mainTracing.c:26-27 */
+
+/* pixel formats of the frame a trace writes */
+enum {
+    GRAFT_OUT_F64_RGB = 0,  /* 3 doubles per pixel: exactly the values the reference passes to pixSetRGB */
+    GRAFT_OUT_F32_RGBA = 1, /* float4 per pixel (r, g, b, 1): one 128-bit store per pixel */
+    GRAFT_OUT_U8_RGBA = 2   /* 4 bytes per pixel, q(v) = (uint8)(min(max(v,0),1)*255 + 0.5), alpha 255 */
+};
+
+/* One shape: the reference's `shape` (shapes.c:14-24) with the function pointers replaced by a kind tag and
+ * the heap `unif` array inlined.  sphere: geom = {cx, cy, cz, radius, -, -} (shapes.c:144-145);
+ * plane: geom = {px, py, pz, nx, ny, nz} (shapes.c:114-115). */
+typedef struct GraftShape {
+    int32_t kind;
+    int32_t reserved;
+    double geom[6];
+    double color[3];     /* unif+4 (sphere, shapes.c:147) or unif+6 (plane, shapes.c:116) */
+    double reflectivity; /* shapes.c:20 */
+    double ambientLight; /* shapes.c:21 */
+    double refrIndex;    /* shapes.c:22 */
+    double transparency; /* shapes.c:23; must be 0: refraction (mainTracing.c:232-294) is not implemented */
+} GraftShape;
+
+/* One light: the reference's `light` (light.c:1-6); the `shape **avoid` list becomes a slice
+ * [avoidOffset, avoidOffset + avoidNum) of GraftScene.avoidIndex holding indices into GraftScene.shapes. */
+typedef struct GraftLight {
+    double color[3];
+    double loc[3];
+    int32_t avoidOffset;
+    int32_t avoidNum;
+} GraftLight;
+
+/* numShapes/shapes[], numLights/lights[], backgroundColor, maxDepth: mainTracing.c:35-39, :63-64 */
+typedef struct GraftScene {
+    int32_t numShapes;
+    int32_t numLights;
+    const GraftShape *shapes;
+    const GraftLight *lights;
+    const int32_t *avoidIndex;
+    int32_t avoidIndexLen;
+    int32_t maxDepth;
+    double backgroundColor[3];
+} GraftScene;
+
+/* Camera globals as they stand after camInitialize (mainTracing.c:54-62, :375-384) plus the loop headers of
+ * launchRays: colOffsets/rowOffsets are the values `i` and `j` take at mainTracing.c:392-393 (accumulated
+ * doubles: fill them with graftLoopOffsets), subStepX/Y the sub-pixel steps of mainTracing.c:405-406. */
+typedef struct GraftView {
+    double screenCenter[3];
+    double camPos[3];
+    double viewDir[3];
+    double lrVec[3];
+    double udVec[3];
+    int32_t projectionType;
+    int32_t aliasing;
+    int32_t numPasses;
+    int32_t reserved;
+    double subStepX; /* screenWidth / WIDTH / numPasses  */
+    double subStepY; /* screenHeight / WIDTH / numPasses (the reference divides by WIDTH here too) */
+    int32_t nCols;   /* trip count of the outer loop, mainTracing.c:392 */
+    int32_t nRows;   /* trip count of the inner loop, mainTracing.c:393 */
+    const double *colOffsets;
+    const double *rowOffsets;
+} GraftView;
+
+/* Ray statistics of a trace: closest-hit queries (one per rayIntersectAvoid call, mainTracing.c:128:
+ * primary + shadow + reflection) and ray-shape evaluations (one per shapes[k]->intersection call, :139). */
+typedef struct GraftCounters {
+    uint64_t rays;
+    uint64_t tests;
+} GraftCounters;
+
+typedef struct GraftJob GraftJob; /* a scene + view packed and resident in device memory */
+
+/* ---- library state ---------------------------------------------------------------------------------- */
+
+/* Number of HIP devices visible, or a negative GRAFT_ERR code.  (No reference counterpart: the reference
+ * has no device.) */
+GRAFT_API int graftDeviceCount(void);
+
+/* Bind this process to one GPU and create the library's stream.  Idempotent for the same device.
+ * Stands where pixInitialize stands in the reference's start-up (mainTracing.c:638): call once before
+ * the first launchRays. */
+GRAFT_API int graftInit(int device);
+
+/* Release everything graftInit and live jobs hold.  Stands where objectDestroy stands, mainTracing.c:646-648. */
+GRAFT_API void graftShutdown(void);
+
+/* Text of the last error; never NULL. */
+GRAFT_API const char *graftLastError(void);
+
+/* ---- host-side steps of launchRays (pure CPU, bit-for-bit the reference's arithmetic) --------------- */
+
+/* The values of `for (double i = -extent/2; i < extent/2; i = i + extent/n)` (mainTracing.c:392-393).
+ * Writes at most cap values, returns the trip count (may be n+1 after zooming: the counter is an
+ * accumulated double) or -1 if the loop would not terminate (extent <= 0 or not finite). */
+GRAFT_API int graftLoopOffsets(double extent, int n, double *out, int cap);
+
+/* getScreenCoordX/Y (mainTracing.c:89-100): pixel coordinate of world offset `coord`, n = WIDTH|HEIGHT. */
+GRAFT_API int graftScreenCoord(double coord, int n, double extent);
+
+/* camInitialize (mainTracing.c:375-384) via getNewPoint (:104-114). */
+GRAFT_API void graftCamInitialize(const double target[3], const double viewDir[3], double targetToScreen,
+                                  double screenToCam, double screenCenter[3], double camPos[3]);
+
+/* ---- the path -------------------------------------------------------------------------------------- */
+
+/* Validate, pack (shapes to per-kind geometry arrays + materials, avoid lists to indices) and upload a scene
+ * and view.  The job owns device memory only; no host pointer is retained.  Replaces the implicit "read the
+ * globals" of launchRays (mainTracing.c:387-391). */
+GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, GraftJob **job);
+
+GRAFT_API void graftJobDestroy(GraftJob *job);
+
+/* Trace loop rows [row0, row0+nRows) of the job's frame into DEVICE memory: `frame` holds nRows*nCols pixels
+ * of `format`, row-major in iy then ix; `hitIndex` (optional, may be NULL) nRows*nCols int32 closest-shape
+ * indices (-1 = miss) of each pixel's first primary ray (the mask of rayIntersect, mainTracing.c:157, over
+ * the rays of :425-437 when anti-aliasing is off); `counters` (optional) one GraftCounters in device memory,
+ * ADDED to.  Asynchronous on `stream` (a hipStream_t; NULL = the library's stream).  This is the double loop
+ * of mainTracing.c:392-441 for those rows. */
+GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int32_t *hitIndex,
+                            GraftCounters *counters, void *stream);
+
+/* Block until everything queued on the library's stream has finished. */
+GRAFT_API int graftSynchronize(void);
+
+/* One-shot convenience for host callers: create a job, trace rows [row0,row0+nRows) and copy the result to
+ * HOST buffers (frame in `format`; hitIndex and counters optional).  This is what a launchRays() drop-in
+ * calls once per frame. */
+GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
+                              void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost);
+
+/* Bytes per pixel of a GRAFT_OUT_* format, 0 if unknown. */
+GRAFT_API size_t graftPixelBytes(int format);
+
+/* Probe kernels used by the numerics tests: out[i] = sqrt(a[i]) and out[i] = a[i] / b[i] evaluated on the
+ * device (host pointers, n elements).  The path relies on both being correctly rounded, as libm sqrt and
+ * the x86 divide are for the reference (vector.c:67-82, shapes.c:58, :88). */
+GRAFT_API int graftProbeSqrt(const double *a, double *out, size_t n);
+GRAFT_API int graftProbeDiv(const double *a, const double *b, double *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAFTHIP_H */

@@ -1,0 +1,401 @@
+/*
+ * rt_oracle.c -- CPU restatement of the launchRays() path of walker-a/RayTracing.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (raytracing_amd/, include/) may include, link or call
+ * this file; it is the checker that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg compare
+ * the HIP path against.
+ *
+ * Parity status: PINNED.  tests/test_oracle_*.py hold this file bit-for-bit (every double of every pixel,
+ * every closest-shape index) against frames produced by the real reference compiled in place from
+ * /root/reference (oracle/Makefile, oracle/gen_golden.py; fixtures under tests/golden/).  The reference has
+ * no tests or golden vectors of its own.
+ *
+ * Every function names the reference lines it follows.  The arithmetic is IEEE double, evaluated in the
+ * reference's order; build with -O3 -ffp-contract=off and never with fast-math.  Differences of FORM
+ * (not of results) from the reference:
+ *   - the scene is passed in a struct instead of file-scope globals, so rows can be traced on several
+ *     threads (the reference is single-threaded; results do not depend on the order pixels are traced in);
+ *   - shapes carry a kind tag instead of function pointers, avoid lists hold indices instead of pointers;
+ *   - mainTracing.c:323 (a copy out of an uninitialised array over the surface colour, deleted by the
+ *     optimiser in the reference's own `clang -O3` build) is a no-op here;
+ *   - transparency > 0 (refraction/fresnel, mainTracing.c:232-294) is not restated: oracle_render refuses it.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KIND_SPHERE 0
+#define KIND_PLANE 1
+#define PROJ_ORTHOGRAPHIC 0 /* mainTracing.c:23 */
+#define PROJ_PERSPECTIVE 1  /* mainTracing.c:24 */
+
+typedef struct OracleJob {
+    /* shapes: kind[n]; unif[n][9] = sphere {cx,cy,cz,r,R,G,B,-,-} (shapes.c:144-147) or
+     * plane {px,py,pz,nx,ny,nz,R,G,B} (shapes.c:114-116); material[n][4] = reflectivity, ambientLight,
+     * refrIndex, transparency (shapes.c:20-23) */
+    int32_t numShapes;
+    int32_t numLights;
+    const int32_t *kind;
+    const double *unif;
+    const double *material;
+    /* lights: color[m][3], loc[m][3] (light.c:1-6); avoid list of light i = avoidIdx[avoidOff[i]..avoidOff[i+1]) */
+    const double *lightColor;
+    const double *lightLoc;
+    const int32_t *avoidOff;
+    const int32_t *avoidIdx;
+    double background[3]; /* mainTracing.c:63 */
+    double screenCenter[3], camPos[3], viewDir[3], lrVec[3], udVec[3]; /* mainTracing.c:57-62 */
+    int32_t maxDepth;       /* mainTracing.c:64 */
+    int32_t projectionType; /* mainTracing.c:29 */
+    int32_t aliasing;       /* mainTracing.c:30 */
+    int32_t numPasses;      /* mainTracing.c:31 */
+    double subStepX;        /* screenWidth / WIDTH / numPasses,  mainTracing.c:405 */
+    double subStepY;        /* screenHeight / WIDTH / numPasses (sic), mainTracing.c:406 */
+    int32_t nCols, nRows;   /* trip counts of the loops at mainTracing.c:392-393 */
+    const double *colOff;   /* the values i takes, in order */
+    const double *rowOff;   /* the values j takes, in order */
+} OracleJob;
+
+typedef struct Counters { uint64_t rays, tests, shoots; } Counters;
+
+/* ---- vector.c ---- */
+static inline void v3copy(const double v[3], double out[3]) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; } /* vector.c:18 */
+static inline void v3add(const double v[3], const double w[3], double out[3]) {                               /* vector.c:25 */
+    out[0] = v[0] + w[0]; out[1] = v[1] + w[1]; out[2] = v[2] + w[2];
+}
+static inline void v3sub(const double v[3], const double w[3], double out[3]) { /* vector.c:32 */
+    out[0] = v[0] - w[0]; out[1] = v[1] - w[1]; out[2] = v[2] - w[2];
+}
+static inline void v3scale(double c, const double w[3], double out[3]) { /* vector.c:39 */
+    out[0] = c * w[0]; out[1] = c * w[1]; out[2] = c * w[2];
+}
+static inline double v3dot(const double v[3], const double w[3]) { /* vector.c:57: the sum starts from 0.0 */
+    double acc = 0.0;
+    acc += v[0] * w[0];
+    acc += v[1] * w[1];
+    acc += v[2] * w[2];
+    return acc;
+}
+static inline double v3length(const double v[3]) { return sqrt(v3dot(v, v)); } /* vector.c:67 */
+static inline double v3unit(const double v[3], double out[3]) {                /* vector.c:74: out untouched if |v| == 0 */
+    double mag = v3length(v);
+    if (mag > 0) {
+        double a = v[0] / mag, b = v[1] / mag, c = v[2] / mag;
+        out[0] = a; out[1] = b; out[2] = c;
+    }
+    return mag;
+}
+
+/* mainTracing.c:104-114 */
+static void newPoint(const double start[3], const double dir[3], double dist, double out[3]) {
+    double scalar;
+    double den = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+    if (dist < 0) scalar = -sqrt(dist * dist / den);
+    else scalar = sqrt(dist * dist / den);
+    double longer[3];
+    v3scale(scalar, dir, longer);
+    v3add(start, longer, out);
+}
+
+/* shapes.c:47-73.  0 = hit, 1 = discriminant negative, 2 = both roots behind the origin */
+static int sphereHit(const double *unif, const double s[3], const double d[3], double loc[3], double normal[3]) {
+    double radius = unif[3];
+    double v[3];
+    v3sub(s, unif, v);
+    double vd = v3dot(v, d);
+    double disc = vd * vd - (v3dot(v, v) - radius * radius);
+    if (disc < 0) return 1;
+    disc = sqrt(disc);
+    double far = -vd + disc;
+    double near = -vd - disc;
+    double t = near >= 0 ? near : far;
+    if (t < 0) return 2;
+    double step[3];
+    v3scale(t, d, step);
+    v3add(s, step, loc);
+    double raw[3];
+    v3sub(loc, unif, raw);
+    v3unit(raw, normal);
+    return 0;
+}
+
+/* shapes.c:83-96: no guard on the denominator, no back-face flip */
+static int planeHit(const double *unif, const double l0[3], const double l[3], double loc[3], double normal[3]) {
+    double toPlane[3];
+    v3sub(unif, l0, toPlane);
+    double d = v3dot(toPlane, unif + 3) / v3dot(l, unif + 3);
+    if (d < 0) return 1;
+    v3copy(unif + 3, normal);
+    double step[3];
+    v3scale(d, l, step);
+    v3add(l0, step, loc);
+    return 0;
+}
+
+/* shapes.c:38-40, :99-101 */
+static void surfaceColor(const OracleJob *J, int k, double rgb[3]) {
+    const double *u = J->unif + 9 * (size_t)k;
+    v3copy(J->kind[k] == KIND_SPHERE ? u + 4 : u + 6, rgb);
+}
+
+/* mainTracing.c:128-153 with :116-123; light < 0 means no avoid list (rayIntersect, :157-159) */
+static int closestHit(const OracleJob *J, const double s[3], const double d[3], double hitLoc[3],
+                      double hitNormal[3], int light, Counters *C) {
+    int best = -1;
+    double bestDist = -1;
+    int a0 = 0, a1 = 0;
+    if (light >= 0) { a0 = J->avoidOff[light]; a1 = J->avoidOff[light + 1]; }
+    C->rays++;
+    for (int k = 0; k < J->numShapes; ++k) {
+        int skip = 0;
+        for (int a = a0; a < a1; ++a)
+            if (J->avoidIdx[a] == k) { skip = 1; break; }
+        if (skip) continue;
+        C->tests++;
+        double loc[3], normal[3];
+        const double *u = J->unif + 9 * (size_t)k;
+        int miss = J->kind[k] == KIND_SPHERE ? sphereHit(u, s, d, loc, normal) : planeHit(u, s, d, loc, normal);
+        if (miss == 0) {
+            double span[3];
+            v3sub(loc, s, span);
+            double dist = v3length(span);
+            if (bestDist == -1 || dist < bestDist) {
+                v3copy(loc, hitLoc);
+                v3copy(normal, hitNormal);
+                bestDist = dist;
+                best = k;
+            }
+        }
+    }
+    return best;
+}
+
+static int shoot(const OracleJob *J, const double s[3], const double d[3], double out[3], int depth, Counters *C);
+
+/* mainTracing.c:196-229: the last light that is not shadowed overwrites the result */
+static void diffuse(const OracleJob *J, const double loc[3], const double normal[3], const double surf[3],
+                    double rgb[3], Counters *C) {
+    for (int i = 0; i < J->numLights; ++i) {
+        const double *lloc = J->lightLoc + 3 * i, *lcol = J->lightColor + 3 * i;
+        double toLight[3], dir[3] = {0, 0, 0}, origin[3], tiny[3];
+        v3sub(lloc, loc, toLight);
+        v3unit(toLight, dir);
+        v3scale(.000001, dir, tiny); /* vecNudge, mainTracing.c:163-167 */
+        v3add(loc, tiny, origin);
+        double blockLoc[3] = {0, 0, 0}, unusedNormal[3];
+        int hit = closestHit(J, origin, dir, blockLoc, unusedNormal, i, C);
+        int lit = hit < 0;
+        if (!lit) {
+            double back[3];
+            v3sub(lloc, blockLoc, back);
+            v3unit(back, back);
+            lit = v3dot(back, dir) < 0.1;
+        }
+        if (lit) {
+            double l[3];
+            v3sub(lloc, loc, l);
+            v3unit(l, l);
+            double w = v3dot(l, normal);
+            w = w < 0 ? 0 : w;
+            double c[3] = {lcol[0] * surf[0], lcol[1] * surf[1], lcol[2] * surf[2]};
+            v3scale(w, c, c);
+            v3copy(c, rgb);
+        }
+    }
+}
+
+/* mainTracing.c:300-372 (reflection(): :180-193).  Returns like the reference: -2 at the depth cap, 0 on a
+ * miss, otherwise the closest shape's index. */
+static int shoot(const OracleJob *J, const double s[3], const double d[3], double out[3], int depth, Counters *C) {
+    out[0] = out[1] = out[2] = 0;
+    C->shoots++;
+    if (depth >= J->maxDepth) return -2;
+    double loc[3], normal[3];
+    int k = closestHit(J, s, d, loc, normal, -1, C);
+    if (k == -1) {
+        v3copy(J->background, out);
+        return 0;
+    }
+    const double *mat = J->material + 4 * (size_t)k;
+    double reflectivity = mat[0], ambient = mat[1];
+    double rgb[3];
+    surfaceColor(J, k, rgb);
+
+    double mirror[3] = {0, 0, 0};
+    if (reflectivity > 0) { /* shouldReflect is 1 on every path that exists without transparency */
+        double tint[3], white[3] = {1, 1, 1};
+        v3sub(white, rgb, tint);
+        v3scale(1 - .5, tint, tint);
+        v3add(rgb, tint, tint);
+        /* reflection(), :180-193 */
+        double twice[3], r[3], origin[3], tiny[3], child[3] = {0, 0, 0};
+        v3scale(2 * v3dot(d, normal), normal, twice);
+        v3sub(d, twice, r);
+        v3unit(r, r);
+        v3scale(.000001, r, tiny);
+        v3add(loc, tiny, origin);
+        if (shoot(J, origin, r, child, depth + 1, C) >= 0) v3copy(child, mirror);
+        mirror[0] = tint[0] * mirror[0]; mirror[1] = tint[1] * mirror[1]; mirror[2] = tint[2] * mirror[2];
+    }
+
+    double lighting[3] = {0, 0, 0};
+    diffuse(J, loc, normal, rgb, lighting, C);
+
+    double refraction[3] = {0, 0, 0};
+    double transparency = mat[3];
+    double wDiff = (1 - ambient) * (1 - reflectivity) * (1 - transparency);
+    double wRefl = (1 - ambient) * reflectivity;
+    double wRefr = 0;
+    double amb[3];
+    v3scale(ambient, rgb, amb);
+    v3scale(wRefl, mirror, mirror);
+    v3scale(wDiff, lighting, lighting);
+    v3scale(wRefr, refraction, refraction);
+    v3add(amb, out, out);
+    v3add(lighting, out, out);
+    v3add(mirror, out, out);
+    v3add(refraction, out, out);
+    return k;
+}
+
+/* ray through world offsets (x, y) on the screen plane, mainTracing.c:405-417 / :425-437 */
+static void primaryRay(const OracleJob *J, double x, double y, double origin[3], double dir[3]) {
+    double col[3];
+    newPoint(J->screenCenter, J->lrVec, x, col);
+    newPoint(col, J->udVec, y, origin);
+    if (J->projectionType == PROJ_ORTHOGRAPHIC) {
+        double back[3] = {-J->viewDir[0], -J->viewDir[1], -J->viewDir[2]};
+        v3copy(back, dir);
+        v3unit(dir, dir);
+    } else {
+        v3sub(origin, J->camPos, dir);
+        v3unit(dir, dir);
+    }
+}
+
+/* body of the double loop of launchRays, mainTracing.c:394-440, for loop indices (ix, iy) */
+static void pixel(const OracleJob *J, int ix, int iy, double px[3], Counters *C) {
+    double i = J->colOff[ix], j = J->rowOff[iy];
+    double rgb[3];
+    v3copy(J->background, rgb);
+    double origin[3], dir[3] = {0, 0, 0};
+    if (J->aliasing) {
+        int counter = 0;
+        double sample[3];
+        for (int k = 0; k < J->numPasses; k++) {
+            for (int l = 0; l < J->numPasses; l++) {
+                counter++;
+                primaryRay(J, i + J->subStepX * (k + 1), j + J->subStepY * (l + 1), origin, dir);
+                shoot(J, origin, dir, sample, 0, C);
+                v3add(rgb, sample, rgb);
+            }
+        }
+        /* numPasses == 0 divides 0/0 in the reference; callers keep numPasses >= 1 */
+        px[0] = rgb[0] / counter; px[1] = rgb[1] / counter; px[2] = rgb[2] / counter;
+    } else {
+        primaryRay(J, i, j, origin, dir);
+        shoot(J, origin, dir, rgb, 0, C);
+        v3copy(rgb, px);
+    }
+}
+
+typedef struct Work {
+    const OracleJob *J;
+    int row0, row1;
+    volatile int *next; /* shared row cursor */
+    double *rgb;        /* [(row1-row0)][nCols][3] or NULL */
+    int32_t *index;     /* [(row1-row0)][nCols] or NULL */
+    Counters C;
+} Work;
+
+static void *rowWorker(void *arg) {
+    Work *w = (Work *)arg;
+    const OracleJob *J = w->J;
+    for (;;) {
+        int iy = __sync_fetch_and_add(w->next, 1);
+        if (iy >= w->row1) break;
+        for (int ix = 0; ix < J->nCols; ++ix) {
+            size_t p = (size_t)(iy - w->row0) * J->nCols + ix;
+            if (w->rgb) pixel(J, ix, iy, w->rgb + 3 * p, &w->C);
+            if (w->index) {
+                double origin[3], dir[3] = {0, 0, 0}, loc[3], n[3];
+                Counters scratch = {0, 0, 0};
+                primaryRay(J, J->colOff[ix], J->rowOff[iy], origin, dir);
+                w->index[p] = closestHit(J, origin, dir, loc, n, -1, &scratch);
+            }
+        }
+    }
+    return NULL;
+}
+
+/*
+ * Trace loop rows [row0,row1) of the frame.  rgb (optional) receives what the reference hands to pixSetRGB
+ * for loop indices (ix,iy), laid out [iy-row0][ix][3]; index (optional) receives the closest-shape index
+ * (-1 = miss) of the anti-aliasing-off primary ray of each pixel (mainTracing.c:425-437 + :157).
+ * counters (optional, 3 words) receive: closest-hit queries, ray-shape evaluations, shootRay calls made for rgb.
+ * Returns 0, or -1 if some shape is transparent (not restated).
+ */
+int oracle_render(const OracleJob *J, int row0, int row1, int threads, double *rgb, int32_t *index,
+                  uint64_t *counters) {
+    for (int k = 0; k < J->numShapes; ++k)
+        if (J->material[4 * (size_t)k + 3] > 0) return -1;
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    volatile int next = row0;
+    Work *w = calloc(threads, sizeof(Work));
+    pthread_t *tid = calloc(threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; ++t) {
+        w[t].J = J; w[t].row0 = row0; w[t].row1 = row1; w[t].next = &next; w[t].rgb = rgb; w[t].index = index;
+    }
+    if (threads == 1) rowWorker(&w[0]);
+    else {
+        for (int t = 0; t < threads; ++t) pthread_create(&tid[t], NULL, rowWorker, &w[t]);
+        for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+    }
+    if (counters) {
+        counters[0] = counters[1] = counters[2] = 0;
+        for (int t = 0; t < threads; ++t) {
+            counters[0] += w[t].C.rays; counters[1] += w[t].C.tests; counters[2] += w[t].C.shoots;
+        }
+    }
+    free(w); free(tid);
+    return 0;
+}
+
+/* ---- host-side steps of launchRays restated for checking the product's host logic ---- */
+
+/* values taken by `for (double i = -extent/2; i < extent/2; i = i + extent/n)` (mainTracing.c:392-393);
+ * returns the trip count, writes at most cap values */
+int oracle_loop_offsets(double extent, int n, double *out, int cap) {
+    int count = 0;
+    for (double i = -extent / 2; i < extent / 2; i = i + extent / n) {
+        if (count < cap) out[count] = i;
+        count++;
+        if (count > 4 * n + 16) break; /* extent <= 0 or NaN would never terminate in the reference */
+    }
+    return count;
+}
+
+/* getScreenCoordX / getScreenCoordY, mainTracing.c:89-100 (n = WIDTH or HEIGHT) */
+int oracle_screen_coord(double coord, int n, double extent) {
+    double ratio = n / extent;
+    coord = round(coord * ratio);
+    return coord + n / 2;
+}
+
+/* camInitialize, mainTracing.c:375-384 */
+void oracle_cam_initialize(const double target[3], const double viewDir[3], double toScreen, double toCam,
+                           double screenCenter[3], double camPos[3]) {
+    newPoint(target, viewDir, toScreen, screenCenter);
+    newPoint(screenCenter, viewDir, toCam, camPos);
+}
+
+/* byte-wise FNV-1a 64 (offset basis 0xcbf29ce484222325, prime 0x100000001b3) for frame fingerprints */
+uint64_t oracle_fnv1a64(const void *data, size_t n) {
+    const unsigned char *p = (const unsigned char *)data;
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ULL; }
+    return h;
+}

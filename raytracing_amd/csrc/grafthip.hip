@@ -1,0 +1,800 @@
+// grafthip.hip -- the launchRays() path of the ray tracer on AMD Instinct MI355X (gfx950, wave64).
+//
+// One lane traces one pixel; one wave owns one 8x8 pixel tile; waves pull tiles from a shared cursor until
+// the band is done.  Scene geometry ({cx,cy,cz,r*r} per sphere, {p,n} per plane) is staged once per
+// workgroup into LDS and read by broadcast (all lanes of a wave test the same shape at the same time);
+// materials and lights stay in global memory (read once per shaded hit).  Every arithmetic step is IEEE
+// double in the reference's order: this file must be compiled with -ffp-contract=off so that no mul/add
+// pair is fused (a fused multiply-add changes hit masks in the last bit).
+//
+// The recursion of shootRay (reference mainTracing.c:300-372) is a per-lane state machine with ONE
+// closest-hit site, so lanes that trace primary, shadow and reflection rays share the hot loop.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "grafthip.h"
+
+namespace {
+
+constexpr int kTile = 8;            // 8x8 pixels = one wave64
+constexpr int kMaxDepth = 12;       // levels of the reflection chain kept per lane
+constexpr int kSmallBlock = 256;    // scenes whose geometry fits a quarter of the LDS
+constexpr int kLargeBlock = 1024;   // one workgroup per CU sharing up to the whole LDS
+constexpr size_t kLdsSmall = 36 * 1024;
+constexpr size_t kLdsMax = 152 * 1024;
+
+struct DevRun {  // shapes [firstShape, firstShape+count) are all of `kind`; their geometry starts at slot
+    int kind, firstShape, count, slot;
+};
+
+struct DevMaterial {  // 64 bytes per shape
+    double color[3];
+    double reflectivity, ambientLight, transparency, refrIndex;
+    int slot, kind;
+};
+
+struct DevLight {  // 64 bytes per light
+    double color[3];
+    double loc[3];
+    int avoidFirst;  // the one avoided shape (avoid mode 1) or -1
+    int avoidNum;
+    int pad[2];
+};
+
+struct TraceParams {
+    // camera (mainTracing.c:54-62 after camInitialize)
+    double screenCenter[3], camPos[3], viewDir[3], lrVec[3], udVec[3];
+    double lrDen, udDen;  // dir.dir of lrVec / udVec as getNewPoint forms it (mainTracing.c:107)
+    double background[3];
+    double subStepX, subStepY;
+    int projectionType, aliasing, numPasses, maxDepth;
+    int numShapes, numLights, numRuns, numSpheres;
+    int nCols, nRows;          // whole frame
+    int row0, bandRows;        // rows traced by this launch
+    int tilesX, numTiles;
+    int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
+    int format;
+    const double *geom;
+    const DevRun *runs;
+    const DevMaterial *materials;
+    const DevLight *lights;
+    const unsigned char *avoidMask;  // [numLights][numShapes], avoid mode 2 only
+    const double *colOff, *rowOff;
+    void *frame;
+    int *hitIndex;
+    unsigned long long *counters;  // {rays, tests} or null
+    int *tileCursor;
+};
+
+extern __shared__ __attribute__((aligned(32))) double ldsGeom[];
+
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+enum { M_RADIANCE = 0, M_SHADOW = 1, M_INDEX = 2, M_DONE = 3 };
+
+struct Hit {
+    int idx, slot, kind;
+    double x, y, z;
+};
+
+// vector.c:57-64: the sum starts from 0.0
+__device__ __forceinline__ double dot3(double ax, double ay, double az, double bx, double by, double bz) {
+    double acc = 0.0;
+    acc += ax * bx;
+    acc += ay * by;
+    acc += az * bz;
+    return acc;
+}
+
+// vector.c:74-82: the output is left alone when the length is not positive
+__device__ __forceinline__ void unit3(double vx, double vy, double vz, double &ox, double &oy, double &oz) {
+    double mag = sqrt(dot3(vx, vy, vz, vx, vy, vz));
+    if (mag > 0) {
+        ox = vx / mag;
+        oy = vy / mag;
+        oz = vz / mag;
+    }
+}
+
+// mainTracing.c:104-114 with the denominator dir.dir hoisted (it only depends on dir)
+__device__ __forceinline__ void newPoint(const double start[3], const double dir[3], double den, double dist,
+                                         double out[3]) {
+    double scalar = sqrt(dist * dist / den);
+    if (dist < 0) scalar = -scalar;
+    out[0] = start[0] + scalar * dir[0];
+    out[1] = start[1] + scalar * dir[1];
+    out[2] = start[2] + scalar * dir[2];
+}
+
+// rayIntersectAvoid (mainTracing.c:128-153) over sphereIntersect (shapes.c:47-73) and planeIntersect
+// (shapes.c:83-96).  Candidate normals are not formed here: only the winner's is used (mainTracing.c:146).
+template <int AVOID, bool LDSGEOM>
+__device__ __forceinline__ void closestHit(const TraceParams &P, double sx, double sy, double sz, double dx,
+                                           double dy, double dz, int avoidShape,
+                                           const unsigned char *avoidRow, Hit &h) {
+    const double *geom = LDSGEOM ? (const double *)ldsGeom : P.geom;
+    double minDist = -1;
+    h.idx = -1;
+    h.slot = 0;
+    h.kind = 0;
+    h.x = h.y = h.z = 0;
+    for (int r = 0; r < P.numRuns; ++r) {
+        const DevRun run = P.runs[r];
+        if (run.kind == GRAFT_SPHERE) {
+            const double *sp = geom + 4 * (size_t)run.slot;
+#pragma unroll 4
+            for (int j = 0; j < run.count; ++j) {
+                const double4v c4 = *(const double4v *)(sp + 4 * j);
+                const double cx = c4.x, cy = c4.y, cz = c4.z, rr = c4.w;
+                const double vx = sx - cx, vy = sy - cy, vz = sz - cz;
+                // vecDot's leading "0.0 +" only turns a -0 result into +0; it cannot change b*b or v.v
+                const double b = vx * dx + vy * dy + vz * dz;
+                const double vv = vx * vx + vy * vy + vz * vz;
+                const double disc = b * b - (vv - rr);
+                bool candidate = !(disc < 0);
+                if (AVOID == 1) candidate = candidate && (run.firstShape + j != avoidShape);
+                if (AVOID == 2) candidate = candidate && !(avoidRow && avoidRow[run.firstShape + j]);
+                if (candidate) {
+                    const double q = sqrt(disc);
+                    const double bz = b + 0.0;  // restores the +0 of the reference's dot product
+                    const double tFar = -bz + q;
+                    const double tNear = -bz - q;
+                    const double t = tNear >= 0 ? tNear : tFar;
+                    if (!(t < 0)) {
+                        const double lx = sx + t * dx, ly = sy + t * dy, lz = sz + t * dz;
+                        const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
+                        const double dist = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+                        if (minDist == -1 || dist < minDist) {
+                            minDist = dist;
+                            h.idx = run.firstShape + j;
+                            h.slot = run.slot + j;
+                            h.kind = GRAFT_SPHERE;
+                            h.x = lx; h.y = ly; h.z = lz;
+                        }
+                    }
+                }
+            }
+        } else {
+            const double *pl = geom + 4 * (size_t)P.numSpheres + 6 * (size_t)run.slot;
+            for (int j = 0; j < run.count; ++j) {
+                const double px = pl[6 * j], py = pl[6 * j + 1], pz = pl[6 * j + 2];
+                const double nx = pl[6 * j + 3], ny = pl[6 * j + 4], nz = pl[6 * j + 5];
+                bool skip = false;
+                if (AVOID == 1) skip = (run.firstShape + j == avoidShape);
+                if (AVOID == 2) skip = avoidRow && avoidRow[run.firstShape + j];
+                const double d = dot3(px - sx, py - sy, pz - sz, nx, ny, nz) / dot3(dx, dy, dz, nx, ny, nz);
+                if (!skip && !(d < 0)) {
+                    const double lx = sx + d * dx, ly = sy + d * dy, lz = sz + d * dz;
+                    const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
+                    const double dist = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+                    if (minDist == -1 || dist < minDist) {
+                        minDist = dist;
+                        h.idx = run.firstShape + j;
+                        h.slot = run.slot + j;
+                        h.kind = GRAFT_PLANE;
+                        h.x = lx; h.y = ly; h.z = lz;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ray through world offsets (xo, yo) of the screen plane: mainTracing.c:405-417 / :425-437
+__device__ __forceinline__ void primaryRay(const TraceParams &P, double xo, double yo, double o[3], double d[3]) {
+    double col[3];
+    newPoint(P.screenCenter, P.lrVec, P.lrDen, xo, col);
+    newPoint(col, P.udVec, P.udDen, yo, o);
+    d[0] = d[1] = d[2] = 0;
+    if (P.projectionType == GRAFT_ORTHOGRAPHIC) unit3(-P.viewDir[0], -P.viewDir[1], -P.viewDir[2], d[0], d[1], d[2]);
+    else unit3(o[0] - P.camPos[0], o[1] - P.camPos[1], o[2] - P.camPos[2], d[0], d[1], d[2]);
+}
+
+__device__ __forceinline__ unsigned quant8(double v) {
+    double c = v < 0 ? 0 : (v > 1 ? 1 : v);
+    if (!(v == v)) c = 0;
+    return (unsigned)(c * 255 + 0.5);
+}
+
+template <int AVOID, bool LDSGEOM>
+__global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
+    if (LDSGEOM) {
+        for (int i = threadIdx.x; i < P.geomDoubles; i += blockDim.x) ldsGeom[i] = P.geom[i];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int lx = lane & (kTile - 1), ly = lane >> 3;
+    const int nSamples = P.aliasing ? P.numPasses * P.numPasses : 1;
+    unsigned long long rayCount = 0, testCount = 0;
+
+    for (;;) {
+        int tile = 0;
+        if (lane == 0) tile = atomicAdd(P.tileCursor, 1);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= P.numTiles) break;  // every wave reaches this: the cursor only grows
+        const int ty = tile / P.tilesX, tx = tile - ty * P.tilesX;
+        const int ix = tx * kTile + lx;
+        const int by = ty * kTile + ly;  // row inside the band
+        const int iy = P.row0 + by;
+        const bool inside = ix < P.nCols && by < P.bandRows;
+
+        double acc[3] = {P.background[0], P.background[1], P.background[2]};  // mainTracing.c:395
+        int firstIdx = -1;
+        if (inside) {
+            const double colI = P.colOff[ix], rowJ = P.rowOff[iy];
+            // per-lane machine state
+            int mode, depth = 0, sample = 0, li = 0, sp = 0, hitIdx = -1, litLight = -1;
+            double o[3], d[3];                 // current ray
+            double loc[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, din[3] = {0, 0, 0};  // shaded hit: point, normal, incoming dir
+            double litW = 0;
+            double stk[kMaxDepth * 7];         // per level: P[3], tint[3], wRefl
+
+            auto startSample = [&](int s) {
+                double xo = colI, yo = rowJ;
+                if (P.aliasing) {  // mainTracing.c:401-406: k outer, l inner
+                    const int k = s / P.numPasses, l = s - k * P.numPasses;
+                    xo = colI + P.subStepX * (double)(k + 1);
+                    yo = rowJ + P.subStepY * (double)(l + 1);
+                }
+                primaryRay(P, xo, yo, o, d);
+                depth = 0;
+                sp = 0;
+                mode = M_RADIANCE;
+            };
+            auto startShadow = [&](int light) {  // mainTracing.c:200-205
+                const DevLight &L = P.lights[light];
+                d[0] = d[1] = d[2] = 0;
+                unit3(L.loc[0] - loc[0], L.loc[1] - loc[1], L.loc[2] - loc[2], d[0], d[1], d[2]);
+                o[0] = loc[0] + .000001 * d[0];
+                o[1] = loc[1] + .000001 * d[1];
+                o[2] = loc[2] + .000001 * d[2];
+                mode = M_SHADOW;
+            };
+
+            if (P.hitIndex && P.aliasing) {  // mask ray = the anti-aliasing-off ray of this pixel
+                primaryRay(P, colI, rowJ, o, d);
+                mode = M_INDEX;
+            } else {
+                startSample(0);
+            }
+
+            while (mode != M_DONE) {
+                Hit h;
+                int avoidShape = -1;
+                const unsigned char *avoidRow = nullptr;
+                unsigned avoided = 0;
+                if (AVOID != 0 && mode == M_SHADOW) {
+                    const DevLight &L = P.lights[li];
+                    avoided = (unsigned)L.avoidNum;
+                    if (AVOID == 1) avoidShape = L.avoidFirst;
+                    if (AVOID == 2 && L.avoidNum > 0) avoidRow = P.avoidMask + (size_t)li * P.numShapes;
+                }
+                closestHit<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
+                rayCount++;
+                testCount += (unsigned)P.numShapes - avoided;
+
+                bool finalize = false, unwind = false;
+                double v[3] = {0, 0, 0};
+                if (mode == M_INDEX) {
+                    firstIdx = h.idx;
+                    startSample(0);
+                    continue;
+                }
+                if (mode == M_RADIANCE) {
+                    if (depth == 0 && sample == 0 && !P.aliasing) firstIdx = h.idx;
+                    if (h.idx < 0) {  // mainTracing.c:314-317
+                        v[0] = P.background[0]; v[1] = P.background[1]; v[2] = P.background[2];
+                        unwind = true;
+                    } else {
+                        hitIdx = h.idx;
+                        loc[0] = h.x; loc[1] = h.y; loc[2] = h.z;
+                        din[0] = d[0]; din[1] = d[1]; din[2] = d[2];
+                        nrm[0] = nrm[1] = nrm[2] = 0;
+                        const double *g = LDSGEOM ? (const double *)ldsGeom : P.geom;
+                        if (h.kind == GRAFT_SPHERE) {  // shapes.c:69-71
+                            const double *c = g + 4 * (size_t)h.slot;
+                            unit3(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
+                        } else {  // shapes.c:91
+                            const double *pn = g + 4 * (size_t)P.numSpheres + 6 * (size_t)h.slot + 3;
+                            nrm[0] = pn[0]; nrm[1] = pn[1]; nrm[2] = pn[2];
+                        }
+                        litW = 0;
+                        litLight = -1;
+                        li = 0;
+                        if (P.numLights > 0) startShadow(0);
+                        else finalize = true;
+                    }
+                } else {  // M_SHADOW: mainTracing.c:210-226
+                    const DevLight &L = P.lights[li];
+                    bool lit = h.idx < 0;
+                    if (!lit) {
+                        double bx = L.loc[0] - h.x, by2 = L.loc[1] - h.y, bz = L.loc[2] - h.z;
+                        unit3(bx, by2, bz, bx, by2, bz);
+                        lit = dot3(bx, by2, bz, d[0], d[1], d[2]) < 0.1;
+                    }
+                    if (lit) {  // direction to the light is recomputed by the reference with identical operations
+                        const double w = dot3(d[0], d[1], d[2], nrm[0], nrm[1], nrm[2]);
+                        litW = w < 0 ? 0 : w;
+                        litLight = li;
+                    }
+                    if (++li < P.numLights) startShadow(li);
+                    else finalize = true;
+                }
+
+                if (finalize) {  // mainTracing.c:330-369 for the level whose hit is (hitIdx, loc, nrm, din)
+                    const DevMaterial &m = P.materials[hitIdx];
+                    const double rgb[3] = {m.color[0], m.color[1], m.color[2]};
+                    double light[3] = {0, 0, 0};
+                    if (litLight >= 0) {  // the last unshadowed light overwrites, mainTracing.c:223-225
+                        const DevLight &L = P.lights[litLight];
+                        for (int c = 0; c < 3; ++c) {
+                            double t = L.color[c] * rgb[c];
+                            light[c] = litW * t;
+                        }
+                    }
+                    const double wDiff = (1 - m.ambientLight) * (1 - m.reflectivity) * (1 - m.transparency);
+                    const double wRefl = (1 - m.ambientLight) * m.reflectivity;
+                    double part[3];
+                    for (int c = 0; c < 3; ++c) {
+                        const double amb = m.ambientLight * rgb[c];
+                        const double lit = wDiff * light[c];
+                        part[c] = lit + (amb + 0.0);
+                    }
+                    if (m.reflectivity > 0) {
+                        double *lv = stk + 7 * sp;
+                        for (int c = 0; c < 3; ++c) {
+                            lv[c] = part[c];
+                            const double t = (1 - .5) * (1.0 - rgb[c]);  // mainTracing.c:334-336
+                            lv[3 + c] = rgb[c] + t;
+                        }
+                        lv[6] = wRefl;
+                        sp++;
+                        if (depth + 1 >= P.maxDepth) {  // the child returns -2 at once, mainTracing.c:305-306
+                            unwind = true;              // v stays 0
+                        } else {  // reflection(), mainTracing.c:180-190
+                            const double k2 = 2 * dot3(din[0], din[1], din[2], nrm[0], nrm[1], nrm[2]);
+                            double rx = din[0] - k2 * nrm[0], ry = din[1] - k2 * nrm[1], rz = din[2] - k2 * nrm[2];
+                            unit3(rx, ry, rz, rx, ry, rz);
+                            d[0] = rx; d[1] = ry; d[2] = rz;
+                            o[0] = loc[0] + .000001 * rx;
+                            o[1] = loc[1] + .000001 * ry;
+                            o[2] = loc[2] + .000001 * rz;
+                            depth++;
+                            mode = M_RADIANCE;
+                        }
+                    } else {  // no mirror term: reflectionRGB stays {0,0,0}
+                        for (int c = 0; c < 3; ++c) {
+                            const double mir = wRefl * 0.0;
+                            double out = mir + part[c];
+                            out = (0.0 * 0.0) + out;
+                            v[c] = out;
+                        }
+                        unwind = true;
+                    }
+                }
+
+                if (unwind) {  // return through the pushed levels, innermost first (mainTracing.c:338, :363-369)
+                    while (sp > 0) {
+                        sp--;
+                        const double *lv = stk + 7 * sp;
+                        for (int c = 0; c < 3; ++c) {
+                            double mir = lv[3 + c] * v[c];
+                            mir = lv[6] * mir;
+                            double out = mir + lv[c];
+                            out = (0.0 * 0.0) + out;
+                            v[c] = out;
+                        }
+                    }
+                    if (P.aliasing) {  // mainTracing.c:419
+                        acc[0] = acc[0] + v[0]; acc[1] = acc[1] + v[1]; acc[2] = acc[2] + v[2];
+                    } else {
+                        acc[0] = v[0]; acc[1] = v[1]; acc[2] = v[2];
+                    }
+                    sample++;
+                    if (sample < nSamples) startSample(sample);
+                    else mode = M_DONE;
+                }
+            }
+            if (P.aliasing) {  // mainTracing.c:422-423: counter == numPasses^2
+                const double n = (double)nSamples;
+                acc[0] = acc[0] / n; acc[1] = acc[1] / n; acc[2] = acc[2] / n;
+            }
+            const size_t p = (size_t)by * P.nCols + ix;
+            if (P.format == GRAFT_OUT_F64_RGB) {
+                double *f = (double *)P.frame + 3 * p;
+                f[0] = acc[0]; f[1] = acc[1]; f[2] = acc[2];
+            } else if (P.format == GRAFT_OUT_F32_RGBA) {
+                float4 px = make_float4((float)acc[0], (float)acc[1], (float)acc[2], 1.0f);
+                ((float4 *)P.frame)[p] = px;
+            } else {
+                unsigned w = quant8(acc[0]) | (quant8(acc[1]) << 8) | (quant8(acc[2]) << 16) | 0xff000000u;
+                ((unsigned *)P.frame)[p] = w;
+            }
+            if (P.hitIndex) P.hitIndex[p] = firstIdx;
+        }
+    }
+    if (P.counters) {
+        for (int off = 32; off > 0; off >>= 1) {
+            rayCount += __shfl_down(rayCount, off);
+            testCount += __shfl_down(testCount, off);
+        }
+        if (lane == 0) {
+            atomicAdd(P.counters, rayCount);
+            atomicAdd(P.counters + 1, testCount);
+        }
+    }
+}
+
+__global__ void probeSqrtKernel(const double *a, double *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sqrt(a[i]);
+}
+__global__ void probeDivKernel(const double *a, const double *b, double *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] / b[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+
+char gError[512] = "no error";
+int gDevice = -1;
+int gNumCU = 0;
+hipStream_t gStream = nullptr;
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(gError, sizeof gError, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(GRAFT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+typedef void (*TraceFn)(const TraceParams);
+
+TraceFn pickKernel(int avoidMode, bool lds) {
+    switch (avoidMode * 2 + (lds ? 1 : 0)) {
+        case 0: return traceKernel<0, false>;
+        case 1: return traceKernel<0, true>;
+        case 2: return traceKernel<1, false>;
+        case 3: return traceKernel<1, true>;
+        case 4: return traceKernel<2, false>;
+        default: return traceKernel<2, true>;
+    }
+}
+
+}  // namespace
+
+struct GraftJob {
+    TraceParams P;
+    int avoidMode;
+    bool lds;
+    size_t ldsBytes;
+    int block;
+    void *arena;  // one device allocation holding every table
+};
+
+extern "C" {
+
+GRAFT_API int graftDeviceCount(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        fail(GRAFT_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+        return -GRAFT_ERR_HIP;
+    }
+    return n;
+}
+
+GRAFT_API int graftInit(int device) {
+    if (gDevice == device && gStream) return GRAFT_OK;
+    if (gDevice >= 0) return fail(GRAFT_ERR_STATE, "graftInit: already bound to device %d", gDevice);
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(GRAFT_ERR_ARG, "graftInit: device %d of %d", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    gNumCU = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&gStream, hipStreamNonBlocking));
+    for (int a = 0; a < 3; ++a)
+        HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kLdsMax));
+    gDevice = device;
+    return GRAFT_OK;
+}
+
+GRAFT_API void graftShutdown(void) {
+    if (gStream) {
+        (void)hipStreamSynchronize(gStream);
+        (void)hipStreamDestroy(gStream);
+    }
+    gStream = nullptr;
+    gDevice = -1;
+}
+
+GRAFT_API const char *graftLastError(void) { return gError; }
+
+GRAFT_API size_t graftPixelBytes(int format) {
+    switch (format) {
+        case GRAFT_OUT_F64_RGB: return 24;
+        case GRAFT_OUT_F32_RGBA: return 16;
+        case GRAFT_OUT_U8_RGBA: return 4;
+        default: return 0;
+    }
+}
+
+// ---- host-side steps of launchRays ----
+
+GRAFT_API int graftLoopOffsets(double extent, int n, double *out, int cap) {
+    if (!(extent > 0) || !std::isfinite(extent) || n <= 0) return -1;
+    int count = 0;
+    for (double i = -extent / 2; i < extent / 2; i = i + extent / n) {  // mainTracing.c:392
+        if (out && count < cap) out[count] = i;
+        if (++count > 2 * n + 16) return -1;
+    }
+    return count;
+}
+
+GRAFT_API int graftScreenCoord(double coord, int n, double extent) {  // mainTracing.c:89-100
+    double ratio = n / extent;
+    coord = round(coord * ratio);
+    return (int)(coord + n / 2);
+}
+
+static void hostNewPoint(const double start[3], const double dir[3], double dist, double out[3]) {
+    double den = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];  // mainTracing.c:107
+    double scalar = dist < 0 ? -sqrt(dist * dist / den) : sqrt(dist * dist / den);
+    for (int c = 0; c < 3; ++c) out[c] = start[c] + scalar * dir[c];
+}
+
+GRAFT_API void graftCamInitialize(const double target[3], const double viewDir[3], double targetToScreen,
+                                  double screenToCam, double screenCenter[3], double camPos[3]) {
+    double sc[3];
+    hostNewPoint(target, viewDir, targetToScreen, sc);  // mainTracing.c:381
+    hostNewPoint(sc, viewDir, screenToCam, camPos);     // mainTracing.c:383
+    for (int c = 0; c < 3; ++c) screenCenter[c] = sc[c];
+}
+
+// ---- jobs ----
+
+GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, GraftJob **jobOut) {
+    if (!jobOut) return fail(GRAFT_ERR_ARG, "graftJobCreate: null job pointer");
+    *jobOut = nullptr;
+    if (gDevice < 0) return fail(GRAFT_ERR_STATE, "graftJobCreate: call graftInit first");
+    if (!scene || !view) return fail(GRAFT_ERR_ARG, "graftJobCreate: null scene or view");
+    const int nS = scene->numShapes, nL = scene->numLights;
+    if (nS < 0 || nL < 0 || (nS > 0 && !scene->shapes) || (nL > 0 && !scene->lights))
+        return fail(GRAFT_ERR_ARG, "graftJobCreate: bad shape/light arrays (%d shapes, %d lights)", nS, nL);
+    if (view->nCols <= 0 || view->nRows <= 0 || !view->colOffsets || !view->rowOffsets)
+        return fail(GRAFT_ERR_ARG, "graftJobCreate: bad frame %d x %d", view->nCols, view->nRows);
+    if (view->aliasing && view->numPasses < 1)
+        return fail(GRAFT_ERR_ARG, "graftJobCreate: numPasses %d with anti-aliasing on", view->numPasses);
+    if (view->aliasing && view->numPasses > 1024)
+        return fail(GRAFT_ERR_ARG, "graftJobCreate: numPasses %d too large", view->numPasses);
+    if (scene->maxDepth > kMaxDepth)
+        return fail(GRAFT_ERR_UNSUPPORTED, "graftJobCreate: maxDepth %d > %d", scene->maxDepth, kMaxDepth);
+
+    std::vector<DevRun> runs;
+    std::vector<DevMaterial> mats(nS);
+    std::vector<double> sph, pln;
+    for (int k = 0; k < nS; ++k) {
+        const GraftShape &s = scene->shapes[k];
+        if (s.kind != GRAFT_SPHERE && s.kind != GRAFT_PLANE)
+            return fail(GRAFT_ERR_ARG, "graftJobCreate: shape %d has kind %d", k, s.kind);
+        if (s.transparency > 0)
+            return fail(GRAFT_ERR_UNSUPPORTED, "graftJobCreate: shape %d is transparent; refraction is not implemented", k);
+        int slot;
+        if (s.kind == GRAFT_SPHERE) {
+            slot = (int)(sph.size() / 4);
+            sph.insert(sph.end(), {s.geom[0], s.geom[1], s.geom[2], s.geom[3] * s.geom[3]});  // shapes.c:54 radius*radius
+        } else {
+            slot = (int)(pln.size() / 6);
+            pln.insert(pln.end(), s.geom, s.geom + 6);
+        }
+        if (runs.empty() || runs.back().kind != s.kind) runs.push_back({s.kind, k, 0, slot});
+        runs.back().count++;
+        DevMaterial &m = mats[k];
+        for (int c = 0; c < 3; ++c) m.color[c] = s.color[c];
+        m.reflectivity = s.reflectivity; m.ambientLight = s.ambientLight;
+        m.transparency = s.transparency; m.refrIndex = s.refrIndex;
+        m.slot = slot; m.kind = s.kind;
+    }
+    // avoid lists: contains() (mainTracing.c:116-123) is set membership by pointer identity; entries that
+    // name no shape of the scene can never match
+    int avoidMode = 0;
+    std::vector<DevLight> lights(nL);
+    std::vector<unsigned char> mask((size_t)nL * (nS > 0 ? nS : 1) + 1, 0);
+    for (int i = 0; i < nL; ++i) {
+        const GraftLight &l = scene->lights[i];
+        if (l.avoidNum < 0 || l.avoidOffset < 0 || l.avoidOffset + l.avoidNum > scene->avoidIndexLen ||
+            (l.avoidNum > 0 && !scene->avoidIndex))
+            return fail(GRAFT_ERR_ARG, "graftJobCreate: light %d avoid slice [%d,+%d) outside %d", i, l.avoidOffset,
+                        l.avoidNum, scene->avoidIndexLen);
+        DevLight &d = lights[i];
+        memset(&d, 0, sizeof d);
+        for (int c = 0; c < 3; ++c) { d.color[c] = l.color[c]; d.loc[c] = l.loc[c]; }
+        d.avoidFirst = -1;
+        for (int a = 0; a < l.avoidNum; ++a) {
+            const int s = scene->avoidIndex[l.avoidOffset + a];
+            if (s < 0 || s >= nS || mask[(size_t)i * nS + s]) continue;
+            mask[(size_t)i * nS + s] = 1;
+            if (d.avoidNum++ == 0) d.avoidFirst = s;
+        }
+        if (d.avoidNum == 1 && avoidMode < 1) avoidMode = 1;
+        if (d.avoidNum > 1) avoidMode = 2;
+    }
+
+    GraftJob *job = new (std::nothrow) GraftJob();
+    if (!job) return fail(GRAFT_ERR_HIP, "graftJobCreate: out of host memory");
+    TraceParams &P = job->P;
+    memset(&P, 0, sizeof P);
+    for (int c = 0; c < 3; ++c) {
+        P.screenCenter[c] = view->screenCenter[c]; P.camPos[c] = view->camPos[c]; P.viewDir[c] = view->viewDir[c];
+        P.lrVec[c] = view->lrVec[c]; P.udVec[c] = view->udVec[c]; P.background[c] = scene->backgroundColor[c];
+    }
+    P.lrDen = P.lrVec[0] * P.lrVec[0] + P.lrVec[1] * P.lrVec[1] + P.lrVec[2] * P.lrVec[2];
+    P.udDen = P.udVec[0] * P.udVec[0] + P.udVec[1] * P.udVec[1] + P.udVec[2] * P.udVec[2];
+    P.subStepX = view->subStepX; P.subStepY = view->subStepY;
+    P.projectionType = view->projectionType; P.aliasing = view->aliasing ? 1 : 0;
+    P.numPasses = view->numPasses; P.maxDepth = scene->maxDepth;
+    P.numShapes = nS; P.numLights = nL; P.numRuns = (int)runs.size(); P.numSpheres = (int)(sph.size() / 4);
+    P.nCols = view->nCols; P.nRows = view->nRows;
+    P.geomDoubles = (int)(sph.size() + pln.size());
+
+    // one arena: geometry | runs | materials | lights | mask | colOff | rowOff | cursor+counters
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t oGeom = 0, oRuns = align(oGeom + sizeof(double) * (P.geomDoubles + 1));
+    size_t oMat = align(oRuns + sizeof(DevRun) * (runs.size() + 1));
+    size_t oLights = align(oMat + sizeof(DevMaterial) * (nS + 1));
+    size_t oMask = align(oLights + sizeof(DevLight) * (nL + 1));
+    size_t oCol = align(oMask + mask.size() + 1);
+    size_t oRow = align(oCol + sizeof(double) * view->nCols);
+    size_t oCursor = align(oRow + sizeof(double) * view->nRows);
+    size_t total = oCursor + 256;
+    std::vector<unsigned char> host(total, 0);
+    if (!sph.empty()) memcpy(&host[oGeom], sph.data(), sizeof(double) * sph.size());
+    if (!pln.empty()) memcpy(&host[oGeom + sizeof(double) * sph.size()], pln.data(), sizeof(double) * pln.size());
+    if (!runs.empty()) memcpy(&host[oRuns], runs.data(), sizeof(DevRun) * runs.size());
+    if (nS) memcpy(&host[oMat], mats.data(), sizeof(DevMaterial) * nS);
+    if (nL) memcpy(&host[oLights], lights.data(), sizeof(DevLight) * nL);
+    if (!mask.empty()) memcpy(&host[oMask], mask.data(), mask.size());
+    memcpy(&host[oCol], view->colOffsets, sizeof(double) * view->nCols);
+    memcpy(&host[oRow], view->rowOffsets, sizeof(double) * view->nRows);
+
+    hipError_t e = hipMalloc(&job->arena, total);
+    if (e != hipSuccess) {
+        delete job;
+        return fail(GRAFT_ERR_HIP, "hipMalloc(%zu): %s", total, hipGetErrorString(e));
+    }
+    e = hipMemcpy(job->arena, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(job->arena);
+        delete job;
+        return fail(GRAFT_ERR_HIP, "hipMemcpy(scene): %s", hipGetErrorString(e));
+    }
+    unsigned char *base = (unsigned char *)job->arena;
+    P.geom = (const double *)(base + oGeom);
+    P.runs = (const DevRun *)(base + oRuns);
+    P.materials = (const DevMaterial *)(base + oMat);
+    P.lights = (const DevLight *)(base + oLights);
+    P.avoidMask = (const unsigned char *)(base + oMask);
+    P.colOff = (const double *)(base + oCol);
+    P.rowOff = (const double *)(base + oRow);
+    P.tileCursor = (int *)(base + oCursor);
+
+    job->avoidMode = avoidMode;
+    job->ldsBytes = sizeof(double) * (size_t)P.geomDoubles;
+    job->lds = job->ldsBytes <= kLdsMax;
+    job->block = (job->lds && job->ldsBytes > kLdsSmall) ? kLargeBlock : kSmallBlock;
+    *jobOut = job;
+    return GRAFT_OK;
+}
+
+GRAFT_API void graftJobDestroy(GraftJob *job) {
+    if (!job) return;
+    if (gStream) (void)hipStreamSynchronize(gStream);
+    (void)hipFree(job->arena);
+    delete job;
+}
+
+GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int32_t *hitIndex,
+                            GraftCounters *counters, void *stream) {
+    if (!job || !frame) return fail(GRAFT_ERR_ARG, "graftJobTrace: null job or frame");
+    if (gDevice < 0) return fail(GRAFT_ERR_STATE, "graftJobTrace: call graftInit first");
+    if (graftPixelBytes(format) == 0) return fail(GRAFT_ERR_ARG, "graftJobTrace: unknown format %d", format);
+    if (row0 < 0 || nRows <= 0 || row0 + nRows > job->P.nRows)
+        return fail(GRAFT_ERR_ARG, "graftJobTrace: rows [%d,+%d) outside frame of %d rows", row0, nRows, job->P.nRows);
+    hipStream_t s = stream ? (hipStream_t)stream : gStream;
+    TraceParams P = job->P;
+    P.row0 = row0; P.bandRows = nRows; P.format = format;
+    P.frame = frame; P.hitIndex = hitIndex; P.counters = (unsigned long long *)counters;
+    P.tilesX = (P.nCols + kTile - 1) / kTile;
+    const long long tiles = (long long)P.tilesX * ((nRows + kTile - 1) / kTile);
+    if (tiles > 0x7fff0000LL) return fail(GRAFT_ERR_ARG, "graftJobTrace: %lld tiles in one launch", tiles);
+    P.numTiles = (int)tiles;
+    const int wavesPerBlock = job->block / 64;
+    const int blocksPerCU = job->block == kLargeBlock ? 1 : 4;
+    long long wantBlocks = (tiles + wavesPerBlock - 1) / wavesPerBlock;
+    long long maxBlocks = (long long)gNumCU * blocksPerCU;
+    const int grid = (int)(wantBlocks < maxBlocks ? wantBlocks : maxBlocks);
+    HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int), s));
+    TraceFn fn = pickKernel(job->avoidMode, job->lds);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(job->block), job->lds ? job->ldsBytes : 0, s, P);
+    HIP_TRY(hipGetLastError());
+    return GRAFT_OK;
+}
+
+GRAFT_API int graftSynchronize(void) {
+    if (gDevice < 0) return fail(GRAFT_ERR_STATE, "graftSynchronize: call graftInit first");
+    HIP_TRY(hipStreamSynchronize(gStream));
+    return GRAFT_OK;
+}
+
+GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
+                              void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost) {
+    if (!frameHost) return fail(GRAFT_ERR_ARG, "graftRenderRows: null frame");
+    GraftJob *job = nullptr;
+    int rc = graftJobCreate(scene, view, &job);
+    if (rc != GRAFT_OK) return rc;
+    const size_t px = (size_t)(nRows > 0 ? nRows : 0) * job->P.nCols;
+    const size_t frameBytes = px * graftPixelBytes(format);
+    void *dFrame = nullptr;
+    int32_t *dIdx = nullptr;
+    GraftCounters *dCnt = nullptr;
+    hipError_t e = hipSuccess;
+    if (frameBytes == 0) rc = fail(GRAFT_ERR_ARG, "graftRenderRows: empty band or unknown format");
+    if (rc == GRAFT_OK && (e = hipMalloc(&dFrame, frameBytes)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(frame): %s", hipGetErrorString(e));
+    if (rc == GRAFT_OK && hitIndexHost && (e = hipMalloc((void **)&dIdx, px * 4)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(index): %s", hipGetErrorString(e));
+    if (rc == GRAFT_OK && countersHost) {
+        if ((e = hipMalloc((void **)&dCnt, sizeof(GraftCounters))) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(counters): %s", hipGetErrorString(e));
+        else if ((e = hipMemsetAsync(dCnt, 0, sizeof(GraftCounters), gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    if (rc == GRAFT_OK) rc = graftJobTrace(job, row0, nRows, format, dFrame, dIdx, dCnt, nullptr);
+    if (rc == GRAFT_OK && (e = hipMemcpyAsync(frameHost, dFrame, frameBytes, hipMemcpyDeviceToHost, gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(frame): %s", hipGetErrorString(e));
+    if (rc == GRAFT_OK && dIdx && (e = hipMemcpyAsync(hitIndexHost, dIdx, px * 4, hipMemcpyDeviceToHost, gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(index): %s", hipGetErrorString(e));
+    if (rc == GRAFT_OK && dCnt && (e = hipMemcpyAsync(countersHost, dCnt, sizeof(GraftCounters), hipMemcpyDeviceToHost, gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(counters): %s", hipGetErrorString(e));
+    if ((e = hipStreamSynchronize(gStream)) != hipSuccess && rc == GRAFT_OK) rc = fail(GRAFT_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    (void)hipFree(dFrame); (void)hipFree(dIdx); (void)hipFree(dCnt);
+    graftJobDestroy(job);
+    return rc;
+}
+
+static int probe(int which, const double *a, const double *b, double *out, size_t n) {
+    if (gDevice < 0) return fail(GRAFT_ERR_STATE, "probe: call graftInit first");
+    if (!a || !out || (which && !b) || n == 0) return fail(GRAFT_ERR_ARG, "probe: null argument");
+    double *dA = nullptr, *dB = nullptr, *dO = nullptr;
+    HIP_TRY(hipMalloc((void **)&dA, n * 8));
+    HIP_TRY(hipMalloc((void **)&dO, n * 8));
+    HIP_TRY(hipMemcpy(dA, a, n * 8, hipMemcpyHostToDevice));
+    if (which) {
+        HIP_TRY(hipMalloc((void **)&dB, n * 8));
+        HIP_TRY(hipMemcpy(dB, b, n * 8, hipMemcpyHostToDevice));
+    }
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (which) hipLaunchKernelGGL(probeDivKernel, dim3(grid), dim3(256), 0, gStream, dA, dB, dO, n);
+    else hipLaunchKernelGGL(probeSqrtKernel, dim3(grid), dim3(256), 0, gStream, dA, dO, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(gStream));
+    HIP_TRY(hipMemcpy(out, dO, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dO);
+    return GRAFT_OK;
+}
+
+GRAFT_API int graftProbeSqrt(const double *a, double *out, size_t n) { return probe(0, a, nullptr, out, n); }
+GRAFT_API int graftProbeDiv(const double *a, const double *b, double *out, size_t n) { return probe(1, a, b, out, n); }
+
+}  // extern "C"
