@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the launchRays() path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg5|default|single]
+
+One step = one whole frame of the workload: every rank traces its band of rows with the HIP kernel
+(inputs -- packed scene, loop-offset tables -- already resident in HBM) into a float4 framebuffer and, for
+N > 1, the bands are gathered into rank 0's HBM with one RCCL gather.  Prints ONE JSON line on rank 0.
+
+metric  Mrays/s, ray = one closest-hit query (primary + shadow + reflection; rayIntersectAvoid of the
+        reference, mainTracing.c:128), counted by the kernel itself in an untimed pass.
+roofline  the trace kernel is bound by the FP64 vector ALU: achieved = 17 flop x ray-shape tests per launch
+        / mean kernel time (HIP events on the launch stream, inside the timed region); peak 78.6 TFLOP/s
+        = 256 CU x 4 SIMD x 16 FP64 lanes x 2 flop (FMA) x 2.4 GHz.  The bit-exact instruction mix cannot
+        use FMA, so 39.3 TFLOP/s is its real ceiling (reported as frac_nofma).
+cpu_baseline  the CPU oracle (a port of the reference, bit-exact to it) on a bounded sample of rows of the
+        SAME frame, on `cores` host threads; the sampled rows are also compared with the GPU's.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import raytracing_amd  # noqa: E402
+from raytracing_amd import scenes  # noqa: E402
+from raytracing_amd.distributed import band_rows, gather_bands  # noqa: E402
+from raytracing_amd.tracer import GRAFT_OUT_F32_RGBA  # noqa: E402
+
+FLOP_PER_TEST = 17            # FP64 flops of one ray-sphere test on the miss path (shapes.c:52-54)
+PEAK_FP64_VALU = 78.6         # TFLOP/s, FMA counted as 2
+PEAK_FP64_NOFMA = 39.3        # TFLOP/s when every mul and add issues separately
+
+
+def build_workload(name, width=None, height=None):
+    if name in scenes.WORKLOADS:
+        rt = scenes.workload(name, width, height)
+        w = scenes.WORKLOADS[name]
+        desc = "%s: %dx%d, %d random spheres, 4 lights, %s, maxDepth %d" % (
+            name, rt.WIDTH, rt.HEIGHT, w["n"],
+            ("%dx%d regular-grid supersampling" % (w["passes"], w["passes"])) if w["passes"] else "1 spp", w["depth"])
+    elif name == "default":
+        rt = scenes.default_scene(WIDTH=width or 512, HEIGHT=height or 512)
+        desc = "default: reference start-up scene (11 shapes, 1 light), 6x6 supersampling, maxDepth 4"
+    elif name == "single":
+        rt = scenes.single_sphere_scene(aliasing=0, WIDTH=width or 512, HEIGHT=height or 512)
+        desc = "single: 512x512, shape 0 + light 0 of the start-up scene, 1 spp"
+    else:
+        raise SystemExit("unknown workload %r" % name)
+    return rt, desc
+
+
+def cpu_baseline(rt, gpu_band, row0, n_rows, cores, budget_rows):
+    """Oracle on `budget_rows` rows spread over [row0,row0+n_rows); returns the cpu_baseline object."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_binding as ob
+    picks = sorted(set(int(row0 + (i + 0.5) * n_rows / budget_rows) for i in range(budget_rows)))
+    rays = 0
+    secs = 0.0
+    exact = True
+    for r in picks:
+        t0 = time.perf_counter()
+        o = ob.render(rt, r, 1, threads=cores, want_counters=True)
+        secs += time.perf_counter() - t0
+        rays += o["counters"][0]
+        if gpu_band is not None:
+            mine = gpu_band[r - row0, :, :3].cpu().numpy()
+            exact = exact and np.array_equal(mine, o["rgb"][0].astype(np.float32))
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d of %d rows of the same frame (evenly spaced), %.1f s of CPU work" % (len(picks), rt.HEIGHT, secs),
+            "sample_matches_gpu": bool(exact)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg4")
+    ap.add_argument("--width", type=int, default=None, help="reduced frame width (debugging)")
+    ap.add_argument("--height", type=int, default=None, help="reduced frame height (debugging)")
+    ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the frame the CPU baseline traces")
+    ap.add_argument("--cpu-cores", type=int, default=16)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    raytracing_amd.init(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    rt, desc = build_workload(args.workload, args.width, args.height)
+    job = rt.create_job()
+    W, H = job.nCols, job.nRows
+    row0, n_rows = band_rows(H, world, rank)
+    if rank == 0:  # rank 0 owns the assembled frame and traces straight into its own rows of it
+        frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+        band = frame[row0:row0 + n_rows]
+    else:
+        frame = None
+        band = torch.empty((n_rows, W, 4), dtype=torch.float32, device=dev)
+    counters = torch.zeros(2, dtype=torch.int64, device=dev)
+    # a real (non-null) stream: kernels, events and the RCCL transfers of the gather are all ordered on it
+    torch_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(torch_stream)
+    stream = torch_stream.cuda_stream
+
+    def step(count=False):
+        job.trace(row0, n_rows, GRAFT_OUT_F32_RGBA, band.data_ptr(), None, counters.data_ptr() if count else None,
+                  stream)
+        if world > 1:
+            gather_bands(band, frame, H, world, rank)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: ray statistics of one frame (the kernel counts its own closest-hit queries and tests)
+    step(count=True)
+    torch.cuda.synchronize()
+    stats = counters.clone()
+    if world > 1:
+        dist.all_reduce(stats)
+    rays, tests = int(stats[0]), int(stats[1])
+    local_tests = int(counters[1])
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        job.trace(row0, n_rows, GRAFT_OUT_F32_RGBA, band.data_ptr(), None, None, stream)
+        ev[k][1].record()
+        if world > 1:
+            gather_bands(band, frame, H, world, rank)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        achieved = FLOP_PER_TEST * local_tests / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/s", "value": rays / (elapsed / args.steps) / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "config": {"workload": desc, "frame": [W, H], "output": "float4 RGBA in HBM",
+                                            "parallelism": "row bands x%d%s" % (world, " + RCCL gather to rank 0" if world > 1 else "")},
+            "rays_per_frame": rays, "tests_per_frame": tests,
+            "primary_Msamples_per_s": W * H * (rt.numPasses ** 2 if rt.aliasing else 1) / (elapsed / args.steps) / 1e6,
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_VALU, "frac_nofma": achieved / PEAK_FP64_NOFMA,
+                         "traffic": None, "kernel": "traceKernel", "kernel_ms": kernel_ms,
+                         "tests_per_launch": local_tests, "flop_per_test": FLOP_PER_TEST},
+        }
+        if world == 1 and not args.no_cpu:
+            rows = args.cpu_rows
+            if rows is None:  # aim at roughly 15 s of CPU work: ~1e8 tests/s per core
+                per_row = max(tests / H, 1.0)
+                rows = int(max(1, min(H, 15.0 * 1.0e8 * args.cpu_cores / per_row)))
+            out["cpu_baseline"] = cpu_baseline(rt, band, row0, n_rows, args.cpu_cores, rows)
+        print(json.dumps(out), flush=True)
+    job.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
