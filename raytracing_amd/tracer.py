@@ -270,6 +270,15 @@ class RayTracer:
         self.udVec = _vecUnit(_mat331Multiply(rot, ud))
 
     def handleKeyDown(self, key, shiftIsDown=0, controlIsDown=0, altOptionIsDown=0, superCommandIsDown=0):
+        """mainTracing.c:552-631: change the globals, clear the display, trace a frame."""
+        if not self.applyKey(key, shiftIsDown):
+            return None
+        self.frame[:] = np.asarray(self.backgroundColor)  # pixClearRGB, :629
+        return self.launchRays()
+
+    def applyKey(self, key, shiftIsDown=0):
+        """The state change of handleKeyDown alone (the switch at mainTracing.c:556-628); False for keys the
+        reference ignores."""
         adjustTheta = 3.14 / 16
         udVector = [0.0, 1.0, 0.0]
         if key == 257 or key == 65:  # ENTER falls through into the 'a' case in the reference (:557-569)
@@ -297,9 +306,8 @@ class RayTracer:
         elif key == 69:
             self.maxDepth = self.maxDepthHigh if self.maxDepth == self.maxDepthLow else self.maxDepthLow
         else:
-            return None
-        self.frame[:] = np.asarray(self.backgroundColor)  # pixClearRGB, :629
-        return self.launchRays()
+            return False
+        return True
 
     def getScreenCoordX(self, coord):  # :89-93
         return lib.graftScreenCoord(float(coord), self.WIDTH, float(self.screenWidth))
