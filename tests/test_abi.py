@@ -1,0 +1,60 @@
+"""The C-ABI shared library loads without a GPU and exports every entry point include/grafthip.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "grafthip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.findall(r"GRAFT_API\s+[\w\s\*]+?\b(graft\w+)\s*\(", text)
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_functions()
+    for must in ("graftInit", "graftShutdown", "graftLastError", "graftJobCreate", "graftJobTrace",
+                 "graftJobDestroy", "graftRenderRows", "graftLoopOffsets", "graftScreenCoord", "graftCamInitialize"):
+        assert must in names
+    assert len(names) == len(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    from raytracing_amd._lib import LIB_PATH
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), "libgrafthip.so does not export %s" % name
+
+
+def test_struct_layouts_match_the_header():
+    """ctypes mirrors must have the sizes the C compiler gives the header's structs."""
+    import subprocess
+    import tempfile
+    from raytracing_amd import _lib
+    src = '#include <stdio.h>\n#include "grafthip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(GraftShape),' \
+          ' sizeof(GraftLight), sizeof(GraftScene), sizeof(GraftView), sizeof(GraftCounters));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert sizes == [ctypes.sizeof(_lib.GraftShape), ctypes.sizeof(_lib.GraftLight), ctypes.sizeof(_lib.GraftScene),
+                     ctypes.sizeof(_lib.GraftView), ctypes.sizeof(_lib.GraftCounters)]
+
+
+def test_compute_entry_points_fail_loudly_without_init():
+    """No CPU fallback: before graftInit (or with no GPU) the compute entry points return an error code."""
+    import raytracing_amd
+    from raytracing_amd._lib import GRAFT_OK, lib
+    from raytracing_amd.tracer import _bound_device
+    if _bound_device is not None:
+        return  # a GPU session already bound the library in this process
+    rt = raytracing_amd.RayTracer(64, 64)
+    rt.sceneInitialize([0, 0, 0], 256, 1000)
+    scene, view, keep = rt.pack()
+    job = ctypes.c_void_p()
+    rc = lib.graftJobCreate(ctypes.byref(scene), ctypes.byref(view), ctypes.byref(job))
+    assert rc != GRAFT_OK and not job.value
+    assert b"graftInit" in lib.graftLastError()

@@ -1,0 +1,53 @@
+"""Frame assembly across ranks (the N > 1 path of bench.py) on CPU: gloo backend, world size 2 and 3.
+Band contents are synthetic (rank- and position-coded); no tracing happens here."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracing_amd.distributed import band_rows, gather_bands
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_rows, n_cols, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        start, count = band_rows(n_rows, world, rank)
+        frame = torch.full((n_rows, n_cols, 4), -1.0) if rank == 0 else None
+        for step in range(2):  # twice: the buffers are reused frame after frame
+            if rank == 0:
+                band = frame[start:start + count]
+            else:
+                band = torch.empty((count, n_cols, 4))
+            rows = torch.arange(start, start + count, dtype=torch.float32).view(-1, 1, 1)
+            cols = torch.arange(n_cols, dtype=torch.float32).view(1, -1, 1)
+            band.copy_((rows * 1000 + cols + step * 0.5).expand(count, n_cols, 4))
+            gather_bands(band, frame, n_rows, world, rank)
+            dist.barrier()
+            if rank == 0:
+                want = (torch.arange(n_rows, dtype=torch.float32).view(-1, 1, 1) * 1000 +
+                        torch.arange(n_cols, dtype=torch.float32).view(1, -1, 1) + step * 0.5).expand(n_rows, n_cols, 4)
+                ret[step] = bool(torch.equal(frame, want))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_rows", [(2, 64), (2, 20), (3, 40), (2, 8)])
+def test_gather_bands(world, n_rows):
+    port = _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(world, port, n_rows, 24, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}

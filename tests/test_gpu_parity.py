@@ -57,3 +57,99 @@ def test_single_sphere(gpu):
     rt = scenes.single_sphere_scene(aliasing=ANTIALIASING_OFF)
     rgb, idx = assert_parity(rt)
     assert np.count_nonzero(idx == 0) == 16497 and np.count_nonzero(idx == -1) == 245647
+
+
+# ---- every golden case (vectors made from the real reference) through the GPU path -------------------------
+
+from cases import CASES, build  # noqa: E402
+from golden_util import check_against_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_matches_reference_golden(gpu, name):
+    rt = build(name)
+    rgb, idx = rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_index=True)
+    cols, rows = rt.loop_offsets()
+    frame, _ = check_against_golden(name, rt, rgb, idx, cols, rows)
+    # the host mirror's own launchRays() (product code path for the pixSetRGB replay) shows the same frame
+    rt.frame[:] = np.asarray(rt.backgroundColor)
+    shown = rt.launchRays()
+    assert np.array_equal(shown.view(np.uint64), frame.view(np.uint64))
+
+
+@pytest.mark.parametrize("name", ["cfg3_512", "cfg5_128_depth4", "mixed_1", "mixed_4_aa2_depth10", "keys_07",
+                                  "parallel_planes_ortho", "camera_inside_sphere"])
+def test_gpu_matches_oracle_counters(gpu, name):
+    assert_parity(build(name))
+
+
+def test_output_formats(gpu):
+    rt = build("mixed_2")
+    f64 = rt.render_rows(0, None, GRAFT_OUT_F64_RGB)
+    f32 = rt.render_rows(0, None, GRAFT_OUT_F32_RGBA)
+    u8 = rt.render_rows(0, None, GRAFT_OUT_U8_RGBA)
+    assert np.array_equal(f32[..., :3], f64.astype(np.float32)) and np.all(f32[..., 3] == 1.0)
+    assert np.array_equal(u8[..., :3], quant8(f64)) and np.all(u8[..., 3] == 255)
+
+
+def test_bands_equal_whole_frame(gpu):
+    """Row bands traced separately (any split, tile-aligned or not) assemble to the frame traced at once."""
+    rt = build("small_96x64_aa3")
+    whole, widx = rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_index=True)
+    for cuts in ([0, 32, 64], [0, 8, 16, 40, 64], [0, 5, 23, 64], [0, 1, 2, 63, 64]):
+        parts = [rt.render_rows(a, b - a, GRAFT_OUT_F64_RGB, want_index=True) for a, b in zip(cuts, cuts[1:])]
+        assert np.array_equal(np.concatenate([p[0] for p in parts]).view(np.uint64), whole.view(np.uint64))
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), widx)
+
+
+def test_device_sqrt_and_divide_are_correctly_rounded(gpu):
+    """The path needs IEEE sqrt and divide on the device (vector.c:67-82, shapes.c:58, :88 on the CPU)."""
+    import ctypes
+    from raytracing_amd._lib import c_double_p, check, lib
+    rng = np.random.default_rng(7)
+    n = 1 << 20
+    a = np.concatenate([rng.uniform(0, 4, n // 4), 10.0 ** rng.uniform(-300, 300, n // 4),
+                        rng.uniform(0, 1e-300, n // 4), np.ldexp(rng.uniform(1, 2, n // 4), rng.integers(-1070, 1020, n // 4))])
+    b = np.concatenate([rng.uniform(-3, 3, n // 2), 10.0 ** rng.uniform(-200, 200, n // 2)])
+    rng.shuffle(b)
+    a[:8] = [0.0, -0.0, np.inf, np.nan, -1.0, 1.0, 5e-324, 1.7976931348623157e308]
+    b[:8] = [0.0, 1.0, np.inf, 2.0, 0.0, -0.0, 3.0, 0.5]
+    out = np.zeros(n)
+    check(lib.graftProbeSqrt(a.ctypes.data_as(c_double_p), out.ctypes.data_as(c_double_p), n))
+    with np.errstate(all="ignore"):
+        want = np.sqrt(a)
+    assert np.array_equal(out.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)])
+    assert np.all(np.isnan(out[np.isnan(want)]))
+    check(lib.graftProbeDiv(a.ctypes.data_as(c_double_p), b.ctypes.data_as(c_double_p), out.ctypes.data_as(c_double_p), n))
+    with np.errstate(all="ignore"):
+        want = a / b
+    assert np.array_equal(out.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)])
+    assert np.all(np.isnan(out[np.isnan(want)]))
+
+
+def test_full_size_rows_match_oracle(gpu):
+    """At the full frame sizes of the measured workloads the oracle cannot trace the whole frame in seconds:
+    compare evenly spaced whole rows bit-for-bit instead."""
+    for name, rows in (("cfg3", (0, 1377, 2048, 4095)), ("cfg5", (4099,)), ("cfg4", (8191,))):
+        rt = scenes.workload(name)
+        for r in rows:
+            want = ob.render(rt, r, 1, threads=THREADS, want_index=True)
+            rgb, idx = rt.render_rows(r, 1, GRAFT_OUT_F64_RGB, want_index=True)
+            assert np.array_equal(idx, want["index"]), (name, r)
+            assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64)), (name, r)
+
+
+def test_errors_are_reported(gpu):
+    from raytracing_amd import GraftError
+    rt = build("no_lights")
+    rt.shapes[0].transparency = 0.5
+    with pytest.raises(GraftError) as e:
+        rt.render_rows()
+    assert e.value.code == 2 and "transparent" in str(e.value)
+    rt.shapes[0].transparency = 0.0
+    rt.maxDepth = 99
+    with pytest.raises(GraftError):
+        rt.render_rows()
+    rt.maxDepth = 4
+    with pytest.raises(GraftError):
+        rt.render_rows(60, 10)  # rows outside the frame

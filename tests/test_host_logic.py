@@ -1,0 +1,68 @@
+"""Host-side steps of launchRays in the product (C ABI helpers + the Python mirror) against the oracle's own
+restatement and the golden state recorded from the real reference.  No GPU needed."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from cases import CASES, build
+from golden_util import GOLDEN
+from raytracing_amd.distributed import band_rows
+from raytracing_amd._lib import lib
+
+
+@pytest.mark.parametrize("extent,n", [(512.0, 512), (512.0 * .9, 512), (512.0 * 1.1, 512), (512 * 1.1 * 1.1 * .9, 64),
+                                      (512.0, 40), (512.0, 4096), (512.0, 16384), (460.8 * .9 * .9, 96), (3.7, 7)])
+def test_loop_offsets(extent, n):
+    """Accumulated-double loop counters of mainTracing.c:392-393, including the 513th iteration after zooming."""
+    want = ob.loop_offsets(extent, n)
+    buf = np.zeros(2 * n + 32)
+    count = lib.graftLoopOffsets(extent, n, buf.ctypes.data_as(ob._dp), len(buf))
+    assert count == len(want)
+    assert np.array_equal(buf[:count].view(np.uint64), want.view(np.uint64))
+    for c in want[:: max(1, len(want) // 50)]:
+        assert lib.graftScreenCoord(float(c), n, extent) == ob.screen_coord(c, n, extent)
+
+
+def test_loop_offsets_rejects_loops_that_never_end():
+    for extent in (0.0, -5.0, float("nan"), float("inf")):
+        assert lib.graftLoopOffsets(extent, 16, None, 0) == -1
+
+
+def test_zoom_out_runs_513_iterations():
+    assert len(ob.loop_offsets(512.0 * 1.1, 512)) == 513
+    assert GOLDEN["default_zoom_out"]["calls"] == 513 * 513 and GOLDEN["default_zoom_out"]["out_of_range"] == 1025
+
+
+@pytest.mark.parametrize("name", ["default_aa6", "default_rot_left", "default_zoom_out", "keys_05", "keys_09",
+                                  "keys_15", "mixed_6_rotated"])
+def test_host_state_matches_reference_globals(name):
+    """After the same operations the mirror's globals equal the real reference's (recorded in golden.json),
+    bit for bit: rotateView (sin/cos, mat33AngleAxisRotation), zoom, flag toggles, camInitialize."""
+    rt = build(name)
+    rt.camInitialize(rt.target, rt.targetToScreen, rt.screenToCam)
+    g = GOLDEN[name]["state"]
+    for key in ("viewDir", "lrVec", "udVec", "screenCenter", "camPos", "target"):
+        assert np.array_equal(np.array(getattr(rt, key)).view(np.uint64), np.array(g[key]).view(np.uint64)), key
+    for key in ("screenWidth", "screenHeight", "projectionType", "aliasing", "numPasses", "maxDepth", "numShapes"):
+        assert getattr(rt, key) == g[key], key
+    sc, cp = ob.cam_initialize(rt.target, rt.viewDir, rt.targetToScreen, rt.screenToCam)
+    assert np.array_equal(sc, np.array(rt.screenCenter)) and np.array_equal(cp, np.array(rt.camPos))
+
+
+def test_pack_translates_pointers_to_indices():
+    rt = build("mixed_2")
+    scene, view, keep = rt.pack()
+    assert scene.numShapes == 15 and scene.numLights == 3
+    lights = [scene.lights[i] for i in range(3)]
+    assert [l.avoidNum for l in lights] == [0, 1, 3]
+    assert [scene.avoidIndex[i] for i in range(scene.avoidIndexLen)] == [1, 0, 14, 3]
+    assert [scene.shapes[k].kind for k in range(15)] == [0] * 12 + [1] * 3
+    assert view.nCols == 64 and view.nRows == 64 and view.aliasing == 0
+
+
+@pytest.mark.parametrize("rows,world", [(16384, 8), (4096, 4), (512, 3), (100, 8), (8, 8), (1, 2), (72, 5)])
+def test_band_rows_partition(rows, world):
+    bands = [band_rows(rows, world, r) for r in range(world)]
+    assert bands[0][0] == 0 and sum(n for _, n in bands) == rows
+    for (a, n), (b, _) in zip(bands, bands[1:]):
+        assert a + n == b and (n == 0 or a % 8 == 0)
