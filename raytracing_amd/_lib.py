@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgrafthip.so")
+# GRAFT_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("GRAFT_LIB") or os.path.join(_HERE, "csrc", "libgrafthip.so")
 
 GRAFT_OK, GRAFT_ERR_ARG, GRAFT_ERR_UNSUPPORTED, GRAFT_ERR_HIP, GRAFT_ERR_STATE = range(5)
 GRAFT_SPHERE, GRAFT_PLANE = 0, 1

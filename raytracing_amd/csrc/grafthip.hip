@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -31,6 +32,9 @@ constexpr size_t kLdsMax = 152 * 1024;
 
 struct DevRun {  // shapes [firstShape, firstShape+count) are all of `kind`; their geometry starts at slot
     int kind, firstShape, count, slot;
+    int fslot;    // sphere runs: first entry of the run's block in the single-precision screen table
+    int fcount;   // entries of that block: count rounded up to a multiple of 8 with never-passing dummies
+    int pad[2];
 };
 
 struct DevMaterial {  // 64 bytes per shape
@@ -60,6 +64,9 @@ struct TraceParams {
     int tilesX, numTiles;
     int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
     int format;
+    int filterFloats;          // floats of the single-precision sphere table (4 per sphere + padding), 0 = no filter
+    int pad0;
+    const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
     const double *geom;
     const DevRun *runs;
     const DevMaterial *materials;
@@ -186,6 +193,167 @@ __device__ __forceinline__ void closestHit(const TraceParams &P, double sx, doub
     }
 }
 
+// One exact sphere test + closest-hit update: sphereIntersect (shapes.c:47-73) and the body of the loop of
+// rayIntersectAvoid (mainTracing.c:139-149), for the sphere in geometry slot `slot` (shape index `shape`).
+__device__ __forceinline__ void exactSphere(const double *geom, int slot, int shape, double sx, double sy, double sz,
+                                            double dx, double dy, double dz, double &minDist, Hit &h) {
+    const double4v c4 = *(const double4v *)(geom + 4 * (size_t)slot);
+    const double vx = sx - c4.x, vy = sy - c4.y, vz = sz - c4.z;
+    const double b = vx * dx + vy * dy + vz * dz;
+    const double vv = vx * vx + vy * vy + vz * vz;
+    const double disc = b * b - (vv - c4.w);
+    if (!(disc < 0)) {
+        const double q = sqrt(disc);
+        const double bz = b + 0.0;
+        const double tFar = -bz + q;
+        const double tNear = -bz - q;
+        const double t = tNear >= 0 ? tNear : tFar;
+        if (!(t < 0)) {
+            const double lx = sx + t * dx, ly = sy + t * dy, lz = sz + t * dz;
+            const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
+            const double dist = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+            if (minDist == -1 || dist < minDist) {
+                minDist = dist;
+                h.idx = shape;
+                h.slot = slot;
+                h.kind = GRAFT_SPHERE;
+                h.x = lx; h.y = ly; h.z = lz;
+            }
+        }
+    }
+}
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+#ifndef GRAFT_SCREEN_PACKED
+#define GRAFT_SCREEN_PACKED 1
+#endif
+
+// Single-precision screening value of one sphere for one ray: an approximation of the discriminant
+// b*b - (v.v - r*r) of shapes.c:54 evaluated with fused multiply-adds on operands rounded to float, with the
+// sphere's share of the worst-case error already folded into rho (see packScreenTable).  A value below the
+// ray's threshold PROVES that the double-precision discriminant of the reference is negative.
+__device__ __forceinline__ float screen1(float cx, float cy, float cz, float rho, float sx, float sy, float sz,
+                                         float dx, float dy, float dz) {
+    const float vx = sx - cx, vy = sy - cy, vz = sz - cz;
+    float b = vx * dx;
+    b = __builtin_fmaf(vy, dy, b);
+    b = __builtin_fmaf(vz, dz, b);
+    float vv = vx * vx;
+    vv = __builtin_fmaf(vy, vy, vv);
+    vv = __builtin_fmaf(vz, vz, vv);
+    float t = rho - vv;
+    return __builtin_fmaf(b, b, t);
+}
+
+// the same for two spheres at once in packed single precision (v_pk_add/mul/fma_f32)
+__device__ __forceinline__ float2v screen2(float2v cx, float2v cy, float2v cz, float2v rho, float2v sx, float2v sy,
+                                           float2v sz, float2v dx, float2v dy, float2v dz) {
+    const float2v vx = sx - cx, vy = sy - cy, vz = sz - cz;
+    float2v b = vx * dx;
+    b = __builtin_elementwise_fma(vy, dy, b);
+    b = __builtin_elementwise_fma(vz, dz, b);
+    float2v vv = vx * vx;
+    vv = __builtin_elementwise_fma(vy, vy, vv);
+    vv = __builtin_elementwise_fma(vz, vz, vv);
+    const float2v t = rho - vv;
+    return __builtin_elementwise_fma(b, b, t);
+}
+
+// rayIntersectAvoid with a conservative single-precision screen in front of the exact test.  Every sphere is
+// still visited by every ray, in index order; the screen only skips spheres whose exact discriminant is
+// provably negative (a miss in shapes.c:55-57), so hit masks and hit points are bit-for-bit unchanged.
+// Error budget (u = 2^-24, A = |s|_1 + |c|_1, |d_i| <= 1): rounding s, c, d to float and evaluating in float
+// perturbs the discriminant by at most 24 u A^2 + 2.02 u rho <= 48 u |s|_1^2 + 48 u |c|_1^2 + 2.02 u rho; the
+// reference's own double rounding adds less than 2^-28 of that.  The ray carries 64 u |s|_1^2 (negThreshold),
+// the sphere carries 64 u |c|_1^2 + 2.2 u rho inside rho.  A ray whose coordinates are not finite, huge, or
+// whose direction is not inside the unit cube is not screened at all (the caller takes the exact loop), and
+// a sphere with such coordinates has rho = +inf and always passes.  With those two rules no screening value
+// is ever NaN, so four of them can be merged with max() and tested with one compare.
+template <int AVOID, bool LDSGEOM>
+__device__ __forceinline__ void closestHitScreened(const TraceParams &P, double sx, double sy, double sz, double dx,
+                                                   double dy, double dz, int avoidShape,
+                                                   const unsigned char *avoidRow, float negThreshold, Hit &h) {
+    const float4v *tableF = LDSGEOM ? (const float4v *)ldsGeom : (const float4v *)P.geomF;
+    const double *geom = P.geom;
+    double minDist = -1;
+    h.idx = -1;
+    h.slot = 0;
+    h.kind = 0;
+    h.x = h.y = h.z = 0;
+    const float sxf = (float)sx, syf = (float)sy, szf = (float)sz;
+    const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
+    auto visit = [&](int slot, int shape) {
+        bool skip = false;
+        if (AVOID == 1) skip = shape == avoidShape;
+        if (AVOID == 2) skip = avoidRow && avoidRow[shape];
+        if (!skip) exactSphere(geom, slot, shape, sx, sy, sz, dx, dy, dz, minDist, h);
+    };
+    for (int r = 0; r < P.numRuns; ++r) {
+        const DevRun run = P.runs[r];
+        if (run.kind == GRAFT_SPHERE) {
+            const float4v *sp = tableF + run.fslot;
+            // Four spheres per block; blocks are handled in pairs (A, B) so that each block's registers are
+            // refilled from LDS while the other block is being evaluated, without register copies.  Every run's
+            // part of the table holds a multiple of 8 entries and the table ends with 8 entries of padding.
+            auto block = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j) {
+                float e0, e1, e2, e3;
+#if GRAFT_SCREEN_PACKED
+                // block layout: {cx0 cx1 cy0 cy1} {cz0 cz1 rho0 rho1} {cx2 cx3 cy2 cy3} {cz2 cz3 rho2 rho3}
+                const float2v S0 = {sxf, sxf}, S1 = {syf, syf}, S2 = {szf, szf};
+                const float2v D0 = {dxf, dxf}, D1 = {dyf, dyf}, D2 = {dzf, dzf};
+                const float2v ea = screen2(c0.xy, c0.zw, c1.xy, c1.zw, S0, S1, S2, D0, D1, D2);
+                const float2v eb = screen2(c2.xy, c2.zw, c3.xy, c3.zw, S0, S1, S2, D0, D1, D2);
+                e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
+#else
+                e0 = screen1(c0.x, c0.y, c0.z, c0.w, sxf, syf, szf, dxf, dyf, dzf);
+                e1 = screen1(c1.x, c1.y, c1.z, c1.w, sxf, syf, szf, dxf, dyf, dzf);
+                e2 = screen1(c2.x, c2.y, c2.z, c2.w, sxf, syf, szf, dxf, dyf, dzf);
+                e3 = screen1(c3.x, c3.y, c3.z, c3.w, sxf, syf, szf, dxf, dyf, dzf);
+#endif
+                const float best = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
+                if (!(best < negThreshold)) {  // rare: some lane may hit one of the four
+                    const int k = run.count - j;  // live spheres from j on (the rest of the run's part is padding)
+                    if (k > 0 && !(e0 < negThreshold)) visit(run.slot + j, run.firstShape + j);
+                    if (k > 1 && !(e1 < negThreshold)) visit(run.slot + j + 1, run.firstShape + j + 1);
+                    if (k > 2 && !(e2 < negThreshold)) visit(run.slot + j + 2, run.firstShape + j + 2);
+                    if (k > 3 && !(e3 < negThreshold)) visit(run.slot + j + 3, run.firstShape + j + 3);
+                }
+            };
+            float4v a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
+            for (int j = 0; j < run.fcount; j += 8) {
+                const float4v b0 = sp[j + 4], b1 = sp[j + 5], b2 = sp[j + 6], b3 = sp[j + 7];
+                block(a0, a1, a2, a3, j);
+                a0 = sp[j + 8]; a1 = sp[j + 9]; a2 = sp[j + 10]; a3 = sp[j + 11];
+                block(b0, b1, b2, b3, j + 4);
+            }
+        } else {
+            const double *pl = geom + 4 * (size_t)P.numSpheres + 6 * (size_t)run.slot;
+            for (int j = 0; j < run.count; ++j) {
+                const double px = pl[6 * j], py = pl[6 * j + 1], pz = pl[6 * j + 2];
+                const double nx = pl[6 * j + 3], ny = pl[6 * j + 4], nz = pl[6 * j + 5];
+                bool skip = false;
+                if (AVOID == 1) skip = (run.firstShape + j == avoidShape);
+                if (AVOID == 2) skip = avoidRow && avoidRow[run.firstShape + j];
+                const double d = dot3(px - sx, py - sy, pz - sz, nx, ny, nz) / dot3(dx, dy, dz, nx, ny, nz);
+                if (!skip && !(d < 0)) {
+                    const double lx = sx + d * dx, ly = sy + d * dy, lz = sz + d * dz;
+                    const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
+                    const double dist = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+                    if (minDist == -1 || dist < minDist) {
+                        minDist = dist;
+                        h.idx = run.firstShape + j;
+                        h.slot = run.slot + j;
+                        h.kind = GRAFT_PLANE;
+                        h.x = lx; h.y = ly; h.z = lz;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ray through world offsets (xo, yo) of the screen plane: mainTracing.c:405-417 / :425-437
 __device__ __forceinline__ void primaryRay(const TraceParams &P, double xo, double yo, double o[3], double d[3]) {
     double col[3];
@@ -202,10 +370,15 @@ __device__ __forceinline__ unsigned quant8(double v) {
     return (unsigned)(c * 255 + 0.5);
 }
 
-template <int AVOID, bool LDSGEOM>
+template <int AVOID, bool LDSGEOM, bool SCREEN>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
-    if (LDSGEOM) {
-        for (int i = threadIdx.x; i < P.geomDoubles; i += blockDim.x) ldsGeom[i] = P.geom[i];
+    if (LDSGEOM) {  // stage the table the hot loop reads: the float screen table, or the exact doubles
+        if (SCREEN) {
+            float *dst = (float *)ldsGeom;
+            for (int i = threadIdx.x; i < P.filterFloats; i += blockDim.x) dst[i] = P.geomF[i];
+        } else {
+            for (int i = threadIdx.x; i < P.geomDoubles; i += blockDim.x) ldsGeom[i] = P.geom[i];
+        }
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
@@ -275,7 +448,18 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     if (AVOID == 1) avoidShape = L.avoidFirst;
                     if (AVOID == 2 && L.avoidNum > 0) avoidRow = P.avoidMask + (size_t)li * P.numShapes;
                 }
-                closestHit<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
+                if (SCREEN) {
+                    const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
+                    const bool tame = s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001;
+                    if (tame) {
+                        const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
+                        closestHitScreened<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
+                    } else {  // exact loop over the doubles in global memory
+                        closestHit<AVOID, false>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
+                    }
+                } else {
+                    closestHit<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
+                }
                 rayCount++;
                 testCount += (unsigned)P.numShapes - avoided;
 
@@ -296,7 +480,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         loc[0] = h.x; loc[1] = h.y; loc[2] = h.z;
                         din[0] = d[0]; din[1] = d[1]; din[2] = d[2];
                         nrm[0] = nrm[1] = nrm[2] = 0;
-                        const double *g = LDSGEOM ? (const double *)ldsGeom : P.geom;
+                        const double *g = (LDSGEOM && !SCREEN) ? (const double *)ldsGeom : P.geom;
                         if (h.kind == GRAFT_SPHERE) {  // shapes.c:69-71
                             const double *c = g + 4 * (size_t)h.slot;
                             unit3(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
@@ -465,15 +649,64 @@ int fail(int code, const char *fmt, ...) {
 
 typedef void (*TraceFn)(const TraceParams);
 
-TraceFn pickKernel(int avoidMode, bool lds) {
-    switch (avoidMode * 2 + (lds ? 1 : 0)) {
-        case 0: return traceKernel<0, false>;
-        case 1: return traceKernel<0, true>;
-        case 2: return traceKernel<1, false>;
-        case 3: return traceKernel<1, true>;
-        case 4: return traceKernel<2, false>;
-        default: return traceKernel<2, true>;
+TraceFn pickKernel(int avoidMode, bool lds, bool screen) {
+    switch (avoidMode * 4 + (lds ? 2 : 0) + (screen ? 1 : 0)) {
+        case 0: return traceKernel<0, false, false>;
+        case 1: return traceKernel<0, false, true>;
+        case 2: return traceKernel<0, true, false>;
+        case 3: return traceKernel<0, true, true>;
+        case 4: return traceKernel<1, false, false>;
+        case 5: return traceKernel<1, false, true>;
+        case 6: return traceKernel<1, true, false>;
+        case 7: return traceKernel<1, true, true>;
+        case 8: return traceKernel<2, false, false>;
+        case 9: return traceKernel<2, false, true>;
+        case 10: return traceKernel<2, true, false>;
+        default: return traceKernel<2, true, true>;
     }
+}
+
+// Single-precision screen table.  Per sphere: (float)cx, (float)cy, (float)cz and rho >= r*r + the sphere's share
+// of the screen's worst-case error (64 u |c|_1^2 + 2.2 u rho, u = 2^-24), rounded up; centre 0 and rho = +inf
+// (always passes) for spheres whose coordinates are not finite or are too large for float arithmetic.  Every
+// sphere run gets its own block, padded to a multiple of eight with entries that never pass (rho = -inf), and the
+// table ends with eight more such entries because the hot loop fetches two blocks of four ahead.  Block layout:
+// GRAFT_SCREEN_PACKED = 0: {cx cy cz rho} x 4;  1: {cx0 cx1 cy0 cy1}{cz0 cz1 rho0 rho1}{cx2 cx3 cy2 cy3}{cz2 cz3 rho2 rho3}.
+void packScreenTable(const std::vector<double> &sph, std::vector<DevRun> &runs, std::vector<float> &out) {
+    const double u = 5.9604644775390625e-08;
+    out.clear();
+    auto entry = [&](float *blk, int i, float cx, float cy, float cz, float rho) {
+#if GRAFT_SCREEN_PACKED
+        float *pair = blk + 8 * (i >> 1);
+        const int h = i & 1;
+        pair[0 + h] = cx; pair[2 + h] = cy; pair[4 + h] = cz; pair[6 + h] = rho;
+#else
+        blk[4 * i] = cx; blk[4 * i + 1] = cy; blk[4 * i + 2] = cz; blk[4 * i + 3] = rho;
+#endif
+    };
+    for (DevRun &run : runs) {
+        if (run.kind != GRAFT_SPHERE) continue;
+        run.fslot = (int)(out.size() / 4);
+        run.fcount = (run.count + 7) / 8 * 8;
+        out.resize(out.size() + 4 * (size_t)run.fcount, 0.0f);
+        for (int j = 0; j < run.fcount; ++j) {
+            float *blk = out.data() + 4 * (size_t)run.fslot + 16 * (j / 4);
+            if (j >= run.count) { entry(blk, j % 4, 0.0f, 0.0f, 0.0f, -INFINITY); continue; }
+            const double *c = &sph[4 * (size_t)(run.slot + j)];
+            const double c1 = fabs(c[0]) + fabs(c[1]) + fabs(c[2]);
+            if (c1 < 1e15 && c[3] >= 0 && c[3] < 1e30) {
+                const double want = ((c[3] + 64.0 * u * c1 * c1) / (1.0 - 2.2 * u)) * 1.000001 + 1e-30;
+                float rho = (float)want;
+                if ((double)rho < want) rho = nextafterf(rho, INFINITY);
+                entry(blk, j % 4, (float)c[0], (float)c[1], (float)c[2], rho);
+            } else {
+                entry(blk, j % 4, 0.0f, 0.0f, 0.0f, INFINITY);
+            }
+        }
+    }
+    const size_t body = out.size();
+    out.resize(body + 32, 0.0f);
+    for (int i = 0; i < 8; ++i) entry(out.data() + body + 16 * (i / 4), i % 4, 0.0f, 0.0f, 0.0f, -INFINITY);
 }
 
 }  // namespace
@@ -481,6 +714,7 @@ TraceFn pickKernel(int avoidMode, bool lds) {
 struct GraftJob {
     TraceParams P;
     int avoidMode;
+    bool screen;  // single-precision screen in front of the exact sphere test
     bool lds;
     size_t ldsBytes;
     int block;
@@ -511,8 +745,9 @@ GRAFT_API int graftInit(int device) {
     gNumCU = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&gStream, hipStreamNonBlocking));
     for (int a = 0; a < 3; ++a)
-        HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)kLdsMax));
+        for (int f = 0; f < 2; ++f)
+            HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f != 0),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     gDevice = device;
     return GRAFT_OK;
 }
@@ -605,7 +840,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
             slot = (int)(pln.size() / 6);
             pln.insert(pln.end(), s.geom, s.geom + 6);
         }
-        if (runs.empty() || runs.back().kind != s.kind) runs.push_back({s.kind, k, 0, slot});
+        if (runs.empty() || runs.back().kind != s.kind) runs.push_back({s.kind, k, 0, slot, 0, 0, {0, 0}});
         runs.back().count++;
         DevMaterial &m = mats[k];
         for (int c = 0; c < 3; ++c) m.color[c] = s.color[c];
@@ -655,9 +890,17 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     P.nCols = view->nCols; P.nRows = view->nRows;
     P.geomDoubles = (int)(sph.size() + pln.size());
 
-    // one arena: geometry | runs | materials | lights | mask | colOff | rowOff | cursor+counters
+    // GRAFT_SCREEN=0 in the environment turns the single-precision screen off (diagnostics and A/B timing)
+    const char *env = getenv("GRAFT_SCREEN");
+    const bool screen = !(env && env[0] == '0') && !sph.empty();
+    std::vector<float> tableF;
+    if (screen) packScreenTable(sph, runs, tableF);
+    P.filterFloats = (int)tableF.size();
+
+    // one arena: geometry | float table | runs | materials | lights | mask | colOff | rowOff | cursor+counters
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t oGeom = 0, oRuns = align(oGeom + sizeof(double) * (P.geomDoubles + 1));
+    size_t oGeom = 0, oGeomF = align(oGeom + sizeof(double) * (P.geomDoubles + 1));
+    size_t oRuns = align(oGeomF + sizeof(float) * (tableF.size() + 1));
     size_t oMat = align(oRuns + sizeof(DevRun) * (runs.size() + 1));
     size_t oLights = align(oMat + sizeof(DevMaterial) * (nS + 1));
     size_t oMask = align(oLights + sizeof(DevLight) * (nL + 1));
@@ -668,6 +911,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     std::vector<unsigned char> host(total, 0);
     if (!sph.empty()) memcpy(&host[oGeom], sph.data(), sizeof(double) * sph.size());
     if (!pln.empty()) memcpy(&host[oGeom + sizeof(double) * sph.size()], pln.data(), sizeof(double) * pln.size());
+    if (!tableF.empty()) memcpy(&host[oGeomF], tableF.data(), sizeof(float) * tableF.size());
     if (!runs.empty()) memcpy(&host[oRuns], runs.data(), sizeof(DevRun) * runs.size());
     if (nS) memcpy(&host[oMat], mats.data(), sizeof(DevMaterial) * nS);
     if (nL) memcpy(&host[oLights], lights.data(), sizeof(DevLight) * nL);
@@ -688,6 +932,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     }
     unsigned char *base = (unsigned char *)job->arena;
     P.geom = (const double *)(base + oGeom);
+    P.geomF = (const float *)(base + oGeomF);
     P.runs = (const DevRun *)(base + oRuns);
     P.materials = (const DevMaterial *)(base + oMat);
     P.lights = (const DevLight *)(base + oLights);
@@ -697,7 +942,8 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     P.tileCursor = (int *)(base + oCursor);
 
     job->avoidMode = avoidMode;
-    job->ldsBytes = sizeof(double) * (size_t)P.geomDoubles;
+    job->screen = screen;
+    job->ldsBytes = screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)P.geomDoubles;
     job->lds = job->ldsBytes <= kLdsMax;
     job->block = (job->lds && job->ldsBytes > kLdsSmall) ? kLargeBlock : kSmallBlock;
     *jobOut = job;
@@ -732,7 +978,7 @@ GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void
     long long maxBlocks = (long long)gNumCU * blocksPerCU;
     const int grid = (int)(wantBlocks < maxBlocks ? wantBlocks : maxBlocks);
     HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int), s));
-    TraceFn fn = pickKernel(job->avoidMode, job->lds);
+    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(job->block), job->lds ? job->ldsBytes : 0, s, P);
     HIP_TRY(hipGetLastError());
     return GRAFT_OK;
