@@ -304,19 +304,26 @@ static void pixel(const OracleJob *J, int ix, int iy, double px[3], Counters *C)
 typedef struct Work {
     const OracleJob *J;
     int row0, row1;
-    volatile int *next; /* shared row cursor */
-    double *rgb;        /* [(row1-row0)][nCols][3] or NULL */
-    int32_t *index;     /* [(row1-row0)][nCols] or NULL */
+    volatile long *next; /* shared cursor over (row, column chunk) items */
+    double *rgb;         /* [(row1-row0)][nCols][3] or NULL */
+    int32_t *index;      /* [(row1-row0)][nCols] or NULL */
     Counters C;
 } Work;
 
-static void *rowWorker(void *arg) {
+#define CHUNK_COLS 32 /* pixels of one row handed to a thread at a time */
+
+static void *chunkWorker(void *arg) {
     Work *w = (Work *)arg;
     const OracleJob *J = w->J;
+    const long chunksPerRow = (J->nCols + CHUNK_COLS - 1) / CHUNK_COLS;
+    const long items = chunksPerRow * (w->row1 - w->row0);
     for (;;) {
-        int iy = __sync_fetch_and_add(w->next, 1);
-        if (iy >= w->row1) break;
-        for (int ix = 0; ix < J->nCols; ++ix) {
+        long item = __sync_fetch_and_add(w->next, 1);
+        if (item >= items) break;
+        int iy = w->row0 + (int)(item / chunksPerRow);
+        int x0 = (int)(item % chunksPerRow) * CHUNK_COLS;
+        int x1 = x0 + CHUNK_COLS < J->nCols ? x0 + CHUNK_COLS : J->nCols;
+        for (int ix = x0; ix < x1; ++ix) {
             size_t p = (size_t)(iy - w->row0) * J->nCols + ix;
             if (w->rgb) pixel(J, ix, iy, w->rgb + 3 * p, &w->C);
             if (w->index) {
@@ -335,6 +342,7 @@ static void *rowWorker(void *arg) {
  * for loop indices (ix,iy), laid out [iy-row0][ix][3]; index (optional) receives the closest-shape index
  * (-1 = miss) of the anti-aliasing-off primary ray of each pixel (mainTracing.c:425-437 + :157).
  * counters (optional, 3 words) receive: closest-hit queries, ray-shape evaluations, shootRay calls made for rgb.
+ * Work is handed to `threads` threads in pieces of 32 pixels of one row (pixels are independent).
  * Returns 0, or -1 if some shape is transparent (not restated).
  */
 int oracle_render(const OracleJob *J, int row0, int row1, int threads, double *rgb, int32_t *index,
@@ -343,15 +351,15 @@ int oracle_render(const OracleJob *J, int row0, int row1, int threads, double *r
         if (J->material[4 * (size_t)k + 3] > 0) return -1;
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
-    volatile int next = row0;
+    volatile long next = 0;
     Work *w = calloc(threads, sizeof(Work));
     pthread_t *tid = calloc(threads, sizeof(pthread_t));
     for (int t = 0; t < threads; ++t) {
         w[t].J = J; w[t].row0 = row0; w[t].row1 = row1; w[t].next = &next; w[t].rgb = rgb; w[t].index = index;
     }
-    if (threads == 1) rowWorker(&w[0]);
+    if (threads == 1) chunkWorker(&w[0]);
     else {
-        for (int t = 0; t < threads; ++t) pthread_create(&tid[t], NULL, rowWorker, &w[t]);
+        for (int t = 0; t < threads; ++t) pthread_create(&tid[t], NULL, chunkWorker, &w[t]);
         for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
     }
     if (counters) {
