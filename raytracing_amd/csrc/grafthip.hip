@@ -18,6 +18,8 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <algorithm>
+#include <utility>
 
 #include "grafthip.h"
 
@@ -64,8 +66,11 @@ struct TraceParams {
     int tilesX, numTiles;
     int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
     int format;
-    int filterFloats;          // floats of the single-precision sphere table (4 per sphere + padding), 0 = no filter
+    int filterFloats;          // floats of the single-precision screen table staged in LDS, 0 = no screen
+    int groupEntries;          // grouped screen: entries of the group table (multiple of 8), 0 = not grouped
+    int memberBase;            // grouped screen: first entry (float4 index) of the member table inside the screen table
     int pad0;
+    const int *memberShape;    // grouped screen: shape index of every member-table entry, -1 = padding
     const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
     const double *geom;
     const DevRun *runs;
@@ -212,7 +217,9 @@ __device__ __forceinline__ void exactSphere(const double *geom, int slot, int sh
             const double lx = sx + t * dx, ly = sy + t * dy, lz = sz + t * dz;
             const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
             const double dist = sqrt(dot3(ex, ey, ez, ex, ey, ez));
-            if (minDist == -1 || dist < minDist) {
+            // "first in index order wins a tie" (mainTracing.c:143-144), written so that it also holds when
+            // spheres are visited out of index order (grouped screen); in index order the last clause never fires
+            if (minDist == -1 || dist < minDist || (dist == minDist && shape < h.idx)) {
                 minDist = dist;
                 h.idx = shape;
                 h.slot = slot;
@@ -354,6 +361,92 @@ __device__ __forceinline__ void closestHitScreened(const TraceParams &P, double 
     }
 }
 
+// screening values of the four spheres of one table block
+__device__ __forceinline__ void screenBlock(const float4v c0, const float4v c1, const float4v c2, const float4v c3,
+                                            float sxf, float syf, float szf, float dxf, float dyf, float dzf,
+                                            float &e0, float &e1, float &e2, float &e3) {
+#if GRAFT_SCREEN_PACKED
+    const float2v S0 = {sxf, sxf}, S1 = {syf, syf}, S2 = {szf, szf};
+    const float2v D0 = {dxf, dxf}, D1 = {dyf, dyf}, D2 = {dzf, dzf};
+    const float2v ea = screen2(c0.xy, c0.zw, c1.xy, c1.zw, S0, S1, S2, D0, D1, D2);
+    const float2v eb = screen2(c2.xy, c2.zw, c3.xy, c3.zw, S0, S1, S2, D0, D1, D2);
+    e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
+#else
+    e0 = screen1(c0.x, c0.y, c0.z, c0.w, sxf, syf, szf, dxf, dyf, dzf);
+    e1 = screen1(c1.x, c1.y, c1.z, c1.w, sxf, syf, szf, dxf, dyf, dzf);
+    e2 = screen1(c2.x, c2.y, c2.z, c2.w, sxf, syf, szf, dxf, dyf, dzf);
+    e3 = screen1(c3.x, c3.y, c3.z, c3.w, sxf, syf, szf, dxf, dyf, dzf);
+#endif
+}
+
+// Two-level screen for sphere-only scenes: spheres are sorted along a space-filling curve on the host and cut
+// into groups of 8; each group has a bounding ball (centre g, radius R >= |c_k - g| + r_k for its members, plus a
+// margin of 0.1).  A ray whose screening value for the bounding ball is below its threshold misses the ball by
+// more than the margin, hence (distance to a line is 1-Lipschitz) misses every member's sphere by more than the
+// margin, hence every member's double-precision discriminant in the reference is negative: the whole group is
+// skipped.  Members of the other groups go through the per-sphere screen and the exact test as before.  The
+// margin covers what separates "misses the ball" from "negative computed discriminant": the direction's
+// deviation from unit length (|d.d - 1| < 1e-15 after vecUnit) times b*b, and the reference's own rounding;
+// both are below 2e-4 for coordinates under 1e5, which is what packGroupedTable and the caller require.
+// Spheres are then met out of index order, so ties are broken by index explicitly (exactSphere); without planes
+// and with finite coordinates no distance is NaN, so the winner does not depend on the order of the visits.
+template <int AVOID, bool LDSGEOM>
+__device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double sx, double sy, double sz, double dx,
+                                                  double dy, double dz, int avoidShape,
+                                                  const unsigned char *avoidRow, float negThreshold, Hit &h) {
+    const float4v *groups = LDSGEOM ? (const float4v *)ldsGeom : (const float4v *)P.geomF;
+    const float4v *members = groups + P.memberBase;
+    const double *geom = P.geom;
+    double minDist = -1;
+    h.idx = -1;
+    h.slot = 0;
+    h.kind = 0;
+    h.x = h.y = h.z = 0;
+    const float sxf = (float)sx, syf = (float)sy, szf = (float)sz;
+    const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
+    auto members4 = [&](const float4v *mb, int pos) {
+        float f0, f1, f2, f3;
+        screenBlock(mb[0], mb[1], mb[2], mb[3], sxf, syf, szf, dxf, dyf, dzf, f0, f1, f2, f3);
+        const float best = __builtin_fmaxf(__builtin_fmaxf(f0, f1), __builtin_fmaxf(f2, f3));
+        if (!(best < negThreshold)) {
+#pragma nounroll
+            for (int v = 0; v < 4; ++v) {
+                const float fv = v == 0 ? f0 : v == 1 ? f1 : v == 2 ? f2 : f3;
+                if (!(fv < negThreshold)) {
+                    const int shape = P.memberShape[pos + v];
+                    bool skip = shape < 0;
+                    if (AVOID == 1) skip = skip || shape == avoidShape;
+                    if (AVOID == 2) skip = skip || (avoidRow && shape >= 0 && avoidRow[shape]);
+                    if (!skip) exactSphere(geom, shape, shape, sx, sy, sz, dx, dy, dz, minDist, h);
+                }
+            }
+        }
+    };
+    auto groups4 = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j) {
+        float e0, e1, e2, e3;
+        screenBlock(c0, c1, c2, c3, sxf, syf, szf, dxf, dyf, dzf, e0, e1, e2, e3);
+        const float best = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
+        if (!(best < negThreshold)) {  // some lane's ray comes near one of these four bounding balls
+#pragma nounroll
+            for (int u = 0; u < 4; ++u) {
+                const float eu = u == 0 ? e0 : u == 1 ? e1 : u == 2 ? e2 : e3;
+                if (!(eu < negThreshold)) {
+                    const float4v *mb = members + (size_t)(j + u) * 8;
+                    members4(mb, (j + u) * 8);
+                    members4(mb + 4, (j + u) * 8 + 4);
+                }
+            }
+        }
+    };
+    float4v a0 = groups[0], a1 = groups[1], a2 = groups[2], a3 = groups[3];
+    for (int j = 0; j < P.groupEntries; j += 8) {
+        const float4v b0 = groups[j + 4], b1 = groups[j + 5], b2 = groups[j + 6], b3 = groups[j + 7];
+        groups4(a0, a1, a2, a3, j);
+        a0 = groups[j + 8]; a1 = groups[j + 9]; a2 = groups[j + 10]; a3 = groups[j + 11];
+        groups4(b0, b1, b2, b3, j + 4);
+    }
+}
+
 // ray through world offsets (xo, yo) of the screen plane: mainTracing.c:405-417 / :425-437
 __device__ __forceinline__ void primaryRay(const TraceParams &P, double xo, double yo, double o[3], double d[3]) {
     double col[3];
@@ -370,7 +463,7 @@ __device__ __forceinline__ unsigned quant8(double v) {
     return (unsigned)(c * 255 + 0.5);
 }
 
-template <int AVOID, bool LDSGEOM, bool SCREEN>
+template <int AVOID, bool LDSGEOM, int SCREEN>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
     if (LDSGEOM) {  // stage the table the hot loop reads: the float screen table, or the exact doubles
         if (SCREEN) {
@@ -451,9 +544,10 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 if (SCREEN) {
                     const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
                     const bool tame = s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001;
-                    if (tame) {
+                    if (tame && (SCREEN == 1 || s1 < 1e5)) {
                         const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
-                        closestHitScreened<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
+                        if (SCREEN == 2) closestHitGrouped<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
+                        else closestHitScreened<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
                     } else {  // exact loop over the doubles in global memory
                         closestHit<AVOID, false>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
                     }
@@ -480,7 +574,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         loc[0] = h.x; loc[1] = h.y; loc[2] = h.z;
                         din[0] = d[0]; din[1] = d[1]; din[2] = d[2];
                         nrm[0] = nrm[1] = nrm[2] = 0;
-                        const double *g = (LDSGEOM && !SCREEN) ? (const double *)ldsGeom : P.geom;
+                        const double *g = (LDSGEOM && SCREEN == 0) ? (const double *)ldsGeom : P.geom;
                         if (h.kind == GRAFT_SPHERE) {  // shapes.c:69-71
                             const double *c = g + 4 * (size_t)h.slot;
                             unit3(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
@@ -649,21 +743,14 @@ int fail(int code, const char *fmt, ...) {
 
 typedef void (*TraceFn)(const TraceParams);
 
-TraceFn pickKernel(int avoidMode, bool lds, bool screen) {
-    switch (avoidMode * 4 + (lds ? 2 : 0) + (screen ? 1 : 0)) {
-        case 0: return traceKernel<0, false, false>;
-        case 1: return traceKernel<0, false, true>;
-        case 2: return traceKernel<0, true, false>;
-        case 3: return traceKernel<0, true, true>;
-        case 4: return traceKernel<1, false, false>;
-        case 5: return traceKernel<1, false, true>;
-        case 6: return traceKernel<1, true, false>;
-        case 7: return traceKernel<1, true, true>;
-        case 8: return traceKernel<2, false, false>;
-        case 9: return traceKernel<2, false, true>;
-        case 10: return traceKernel<2, true, false>;
-        default: return traceKernel<2, true, true>;
-    }
+template <int A>
+TraceFn pickKernelA(bool lds, int screen) {
+    if (lds) return screen == 2 ? traceKernel<A, true, 2> : screen == 1 ? traceKernel<A, true, 1> : traceKernel<A, true, 0>;
+    return screen == 2 ? traceKernel<A, false, 2> : screen == 1 ? traceKernel<A, false, 1> : traceKernel<A, false, 0>;
+}
+
+TraceFn pickKernel(int avoidMode, bool lds, int screen) {
+    return avoidMode == 0 ? pickKernelA<0>(lds, screen) : avoidMode == 1 ? pickKernelA<1>(lds, screen) : pickKernelA<2>(lds, screen);
 }
 
 // Single-precision screen table.  Per sphere: (float)cx, (float)cy, (float)cz and rho >= r*r + the sphere's share
@@ -709,12 +796,101 @@ void packScreenTable(const std::vector<double> &sph, std::vector<DevRun> &runs, 
     for (int i = 0; i < 8; ++i) entry(out.data() + body + 16 * (i / 4), i % 4, 0.0f, 0.0f, 0.0f, -INFINITY);
 }
 
+// rho of the screen table for a ball of squared radius rr centred at c (see packScreenTable); false if the
+// coordinates are not finite or too large for float arithmetic
+bool screenRho(const double c[3], double rr, float &rho) {
+    const double u = 5.9604644775390625e-08;
+    const double c1 = fabs(c[0]) + fabs(c[1]) + fabs(c[2]);
+    if (!(c1 < 1e15 && rr >= 0 && rr < 1e30)) return false;
+    const double want = ((rr + 64.0 * u * c1 * c1) / (1.0 - 2.2 * u)) * 1.000001 + 1e-30;
+    rho = (float)want;
+    if ((double)rho < want) rho = nextafterf(rho, INFINITY);
+    return true;
+}
+
+void putEntry(float *blk, int i, float cx, float cy, float cz, float rho) {
+#if GRAFT_SCREEN_PACKED
+    float *pair = blk + 8 * (i >> 1);
+    const int h = i & 1;
+    pair[0 + h] = cx; pair[2 + h] = cy; pair[4 + h] = cz; pair[6 + h] = rho;
+#else
+    blk[4 * i] = cx; blk[4 * i + 1] = cy; blk[4 * i + 2] = cz; blk[4 * i + 3] = rho;
+#endif
+}
+
+constexpr int kGroup = 8;          // spheres per group of the two-level screen
+constexpr double kGroupMargin = 0.1;
+constexpr double kGroupScale = 1e5;  // coordinates must stay below this for the margin to cover the rounding terms
+
+// Two-level screen table for a scene of spheres only (see closestHitGrouped).  Layout, in entries of 4 floats:
+// [group table: bounding balls, 4 per block, padded to a multiple of 8][8 entries of padding: the loop fetches two
+// blocks ahead][member table: 8 entries (2 blocks) per group].  Returns false when the scene does not qualify.
+bool packGroupedTable(const std::vector<double> &sph, std::vector<float> &out, std::vector<int> &memberShape,
+                      int &groupEntries, int &memberBase) {
+    const int n = (int)(sph.size() / 4);
+    if (n < 64) return false;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < n; ++k) {
+        const double *c = &sph[4 * (size_t)k];
+        const double r = sqrt(c[3]);
+        if (!(fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + r < kGroupScale)) return false;  // also rejects NaN
+        for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], c[a]); hi[a] = fmax(hi[a], c[a]); }
+    }
+    // Morton order of the centres (10 bits per axis), ties by index
+    std::vector<std::pair<unsigned, int>> order(n);
+    for (int k = 0; k < n; ++k) {
+        unsigned code = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double span = hi[a] - lo[a];
+            unsigned q = span > 0 ? (unsigned)fmin(1023.0, (sph[4 * (size_t)k + a] - lo[a]) / span * 1024.0) : 0u;
+            for (int b = 0; b < 10; ++b) code |= ((q >> b) & 1u) << (3 * b + a);
+        }
+        order[k] = {code, k};
+    }
+    std::sort(order.begin(), order.end());
+    const int nGroups = (n + kGroup - 1) / kGroup;
+    groupEntries = (nGroups + 7) / 8 * 8;
+    memberBase = groupEntries + 8;
+    out.assign(4 * ((size_t)memberBase + (size_t)nGroups * kGroup + 8), 0.0f);
+    memberShape.assign((size_t)nGroups * kGroup, -1);
+    for (int i = 0; i < memberBase; ++i) putEntry(out.data() + 16 * (i / 4), i % 4, 0.0f, 0.0f, 0.0f, -INFINITY);
+    for (int gI = 0; gI < nGroups; ++gI) {
+        const int first = gI * kGroup, last = std::min(n, first + kGroup);
+        double g[3] = {0, 0, 0};
+        for (int m = first; m < last; ++m)
+            for (int a = 0; a < 3; ++a) g[a] += sph[4 * (size_t)order[m].second + a] / (last - first);
+        double R = 0;
+        for (int m = first; m < last; ++m) {
+            const double *c = &sph[4 * (size_t)order[m].second];
+            const double dx = c[0] - g[0], dy = c[1] - g[1], dz = c[2] - g[2];
+            R = fmax(R, sqrt(dx * dx + dy * dy + dz * dz) + sqrt(c[3]));
+        }
+        R = R * (1.0 + 1e-9) + kGroupMargin;
+        float rho;
+        if (!screenRho(g, R * R * (1.0 + 1e-12), rho)) return false;
+        putEntry(out.data() + 16 * (gI / 4), gI % 4, (float)g[0], (float)g[1], (float)g[2], rho);
+        float *mblk = out.data() + 4 * ((size_t)memberBase + (size_t)gI * kGroup);
+        for (int m = 0; m < kGroup; ++m) {
+            float *blk = mblk + 16 * (m / 4);
+            if (first + m >= last) { putEntry(blk, m % 4, 0.0f, 0.0f, 0.0f, -INFINITY); continue; }
+            const int k = order[first + m].second;
+            const double *c = &sph[4 * (size_t)k];
+            if (!screenRho(c, c[3], rho)) return false;
+            putEntry(blk, m % 4, (float)c[0], (float)c[1], (float)c[2], rho);
+            memberShape[(size_t)gI * kGroup + m] = k;
+        }
+    }
+    const size_t tail = (size_t)memberBase + (size_t)nGroups * kGroup;
+    for (int i = 0; i < 8; ++i) putEntry(out.data() + 4 * tail + 16 * (i / 4), i % 4, 0.0f, 0.0f, 0.0f, -INFINITY);
+    return true;
+}
+
 }  // namespace
 
 struct GraftJob {
     TraceParams P;
     int avoidMode;
-    bool screen;  // single-precision screen in front of the exact sphere test
+    int screen;   // 0 = exact only, 1 = single-precision screen per sphere, 2 = two-level (grouped) screen
     bool lds;
     size_t ldsBytes;
     int block;
@@ -745,8 +921,8 @@ GRAFT_API int graftInit(int device) {
     gNumCU = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&gStream, hipStreamNonBlocking));
     for (int a = 0; a < 3; ++a)
-        for (int f = 0; f < 2; ++f)
-            HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f != 0),
+        for (int f = 0; f < 3; ++f)
+            HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     gDevice = device;
     return GRAFT_OK;
@@ -890,17 +1066,24 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     P.nCols = view->nCols; P.nRows = view->nRows;
     P.geomDoubles = (int)(sph.size() + pln.size());
 
-    // GRAFT_SCREEN=0 in the environment turns the single-precision screen off (diagnostics and A/B timing)
+    // GRAFT_SCREEN in the environment caps the screen level (diagnostics and A/B timing): 0 = exact double loop
+    // only, 1 = single-precision screen per sphere, 2 (default) = two-level screen where the scene qualifies
     const char *env = getenv("GRAFT_SCREEN");
-    const bool screen = !(env && env[0] == '0') && !sph.empty();
+    const int screenCap = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : 2;
+    int screen = (screenCap >= 1 && !sph.empty()) ? 1 : 0;
     std::vector<float> tableF;
-    if (screen) packScreenTable(sph, runs, tableF);
+    std::vector<int> memberShape;
+    if (screen && screenCap >= 2 && pln.empty() &&
+        packGroupedTable(sph, tableF, memberShape, P.groupEntries, P.memberBase)) screen = 2;
+    if (screen != 2) { P.groupEntries = 0; P.memberBase = 0; memberShape.clear(); }
+    if (screen == 1) packScreenTable(sph, runs, tableF);
     P.filterFloats = (int)tableF.size();
 
     // one arena: geometry | float table | runs | materials | lights | mask | colOff | rowOff | cursor+counters
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t oGeom = 0, oGeomF = align(oGeom + sizeof(double) * (P.geomDoubles + 1));
-    size_t oRuns = align(oGeomF + sizeof(float) * (tableF.size() + 1));
+    size_t oMember = align(oGeomF + sizeof(float) * (tableF.size() + 1));
+    size_t oRuns = align(oMember + sizeof(int) * (memberShape.size() + 1));
     size_t oMat = align(oRuns + sizeof(DevRun) * (runs.size() + 1));
     size_t oLights = align(oMat + sizeof(DevMaterial) * (nS + 1));
     size_t oMask = align(oLights + sizeof(DevLight) * (nL + 1));
@@ -912,6 +1095,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     if (!sph.empty()) memcpy(&host[oGeom], sph.data(), sizeof(double) * sph.size());
     if (!pln.empty()) memcpy(&host[oGeom + sizeof(double) * sph.size()], pln.data(), sizeof(double) * pln.size());
     if (!tableF.empty()) memcpy(&host[oGeomF], tableF.data(), sizeof(float) * tableF.size());
+    if (!memberShape.empty()) memcpy(&host[oMember], memberShape.data(), sizeof(int) * memberShape.size());
     if (!runs.empty()) memcpy(&host[oRuns], runs.data(), sizeof(DevRun) * runs.size());
     if (nS) memcpy(&host[oMat], mats.data(), sizeof(DevMaterial) * nS);
     if (nL) memcpy(&host[oLights], lights.data(), sizeof(DevLight) * nL);
@@ -933,6 +1117,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     unsigned char *base = (unsigned char *)job->arena;
     P.geom = (const double *)(base + oGeom);
     P.geomF = (const float *)(base + oGeomF);
+    P.memberShape = (const int *)(base + oMember);
     P.runs = (const DevRun *)(base + oRuns);
     P.materials = (const DevMaterial *)(base + oMat);
     P.lights = (const DevLight *)(base + oLights);
