@@ -1,0 +1,30 @@
+"""Diagnostic: per-wave shader-clock shares of the trace kernel (needs a library built with -DGRAFT_STAMPS).
+    GRAFT_LIB=/path/libgraft_stamps.so python profiles/diag_stamps.py cfg3 [height]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracing_amd
+from raytracing_amd import scenes
+from raytracing_amd.tracer import GRAFT_OUT_F32_RGBA
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+height = int(sys.argv[2]) if len(sys.argv) > 2 else None
+raytracing_amd.init(0)
+rt = scenes.workload(name, None, height)
+job = rt.create_job()
+frame = torch.empty((job.nRows, job.nCols, 4), dtype=torch.float32, device="cuda")
+cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+st = torch.cuda.Stream(); torch.cuda.set_stream(st)
+for _ in range(2):
+    cnt.zero_()
+    job.trace(0, job.nRows, GRAFT_OUT_F32_RGBA, frame.data_ptr(), None, cnt.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+c = cnt.tolist()
+rays, tests, total, hit, rounds, waves, loop = c[:7]
+tiles = ((job.nCols + 7) // 8) * ((job.nRows + 7) // 8)
+print("%s: waves %d, tiles %d, wave-rounds %d (%.1f lanes busy per round), cycles per wave %.3g | shares of wave time: "
+      "closest-hit %.1f%%, rest of the ray loop %.1f%%, outside the loop (tile set-up, ticket, store) %.1f%% | per round: "
+      "closest-hit %.0f cycles, shading/state machine %.0f | per tile outside loop %.0f"
+      % (name, waves, tiles, rounds, rays / max(rounds, 1), total / max(waves, 1), 100.0 * hit / total,
+         100.0 * (loop - hit) / total, 100.0 * (total - loop) / total, hit / max(rounds, 1), (loop - hit) / max(rounds, 1),
+         (total - loop) / tiles))

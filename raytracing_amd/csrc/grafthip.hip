@@ -28,7 +28,10 @@ namespace {
 constexpr int kTile = 8;            // 8x8 pixels = one wave64
 constexpr int kMaxDepth = 12;       // levels of the reflection chain kept per lane
 constexpr int kSmallBlock = 256;    // scenes whose geometry fits a quarter of the LDS
-constexpr int kLargeBlock = 1024;   // one workgroup per CU sharing up to the whole LDS
+#ifndef GRAFT_LARGE_BLOCK
+#define GRAFT_LARGE_BLOCK 1024
+#endif
+constexpr int kLargeBlock = GRAFT_LARGE_BLOCK;   // one workgroup per CU sharing up to the whole LDS
 constexpr size_t kLdsSmall = 36 * 1024;
 constexpr size_t kLdsMax = 152 * 1024;
 
@@ -64,12 +67,13 @@ struct TraceParams {
     int nCols, nRows;          // whole frame
     int row0, bandRows;        // rows traced by this launch
     int tilesX, numTiles;
+    int tilesPerTicket, pad1;  // consecutive tiles a wave takes per draw from the cursor
     int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
     int format;
     int filterFloats;          // floats of the single-precision screen table staged in LDS, 0 = no screen
     int groupEntries;          // grouped screen: entries of the group table (multiple of 8), 0 = not grouped
     int memberBase;            // grouped screen: first entry (float4 index) of the member table inside the screen table
-    int pad0;
+    int exactLdsOffset;        // bytes from the start of LDS to the staged exact doubles (EXACTLDS kernels)
     const int *memberShape;    // grouped screen: shape index of every member-table entry, -1 = padding
     const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
     const double *geom;
@@ -278,12 +282,12 @@ __device__ __forceinline__ float2v screen2(float2v cx, float2v cy, float2v cz, f
 // whose direction is not inside the unit cube is not screened at all (the caller takes the exact loop), and
 // a sphere with such coordinates has rho = +inf and always passes.  With those two rules no screening value
 // is ever NaN, so four of them can be merged with max() and tested with one compare.
-template <int AVOID, bool LDSGEOM>
+template <int AVOID, bool LDSGEOM, bool EXACTLDS>
 __device__ __forceinline__ void closestHitScreened(const TraceParams &P, double sx, double sy, double sz, double dx,
                                                    double dy, double dz, int avoidShape,
                                                    const unsigned char *avoidRow, float negThreshold, Hit &h) {
     const float4v *tableF = LDSGEOM ? (const float4v *)ldsGeom : (const float4v *)P.geomF;
-    const double *geom = P.geom;
+    const double *geom = EXACTLDS ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
     double minDist = -1;
     h.idx = -1;
     h.slot = 0;
@@ -390,13 +394,13 @@ __device__ __forceinline__ void screenBlock(const float4v c0, const float4v c1, 
 // both are below 2e-4 for coordinates under 1e5, which is what packGroupedTable and the caller require.
 // Spheres are then met out of index order, so ties are broken by index explicitly (exactSphere); without planes
 // and with finite coordinates no distance is NaN, so the winner does not depend on the order of the visits.
-template <int AVOID, bool LDSGEOM>
+template <int AVOID, bool LDSGEOM, bool EXACTLDS>
 __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double sx, double sy, double sz, double dx,
                                                   double dy, double dz, int avoidShape,
                                                   const unsigned char *avoidRow, float negThreshold, Hit &h) {
     const float4v *groups = LDSGEOM ? (const float4v *)ldsGeom : (const float4v *)P.geomF;
     const float4v *members = groups + P.memberBase;
-    const double *geom = P.geom;
+    const double *geom = EXACTLDS ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
     double minDist = -1;
     h.idx = -1;
     h.slot = 0;
@@ -463,12 +467,20 @@ __device__ __forceinline__ unsigned quant8(double v) {
     return (unsigned)(c * 255 + 0.5);
 }
 
-template <int AVOID, bool LDSGEOM, int SCREEN>
+// SCREEN: 0 = exact double loop, 1 = single-precision screen per sphere, 2 = two-level screen.
+// LDSGEOM: the table the hot loop reads (screen table, or the doubles when SCREEN == 0) is staged in LDS.
+// EXACTLDS (SCREEN > 0 only): the exact doubles are staged in LDS as well, behind the screen table; otherwise the
+// rare exact tests read them from global memory.
+template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
-    if (LDSGEOM) {  // stage the table the hot loop reads: the float screen table, or the exact doubles
+    if (LDSGEOM) {
         if (SCREEN) {
             float *dst = (float *)ldsGeom;
             for (int i = threadIdx.x; i < P.filterFloats; i += blockDim.x) dst[i] = P.geomF[i];
+            if (EXACTLDS) {
+                double *dd = (double *)((char *)ldsGeom + P.exactLdsOffset);
+                for (int i = threadIdx.x; i < P.geomDoubles; i += blockDim.x) dd[i] = P.geom[i];
+            }
         } else {
             for (int i = threadIdx.x; i < P.geomDoubles; i += blockDim.x) ldsGeom[i] = P.geom[i];
         }
@@ -478,12 +490,26 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     const int lx = lane & (kTile - 1), ly = lane >> 3;
     const int nSamples = P.aliasing ? P.numPasses * P.numPasses : 1;
     unsigned long long rayCount = 0, testCount = 0;
+#ifdef GRAFT_STAMPS  // diagnostic build only: shader-clock cycles per wave in the closest-hit call and in total
+    unsigned long long stampHit = 0, stampRounds = 0, stampLoop = 0;
+    const unsigned long long stampBegin = clock64();
+#endif
 
+    // Tiles are handed out by a shared cursor, `tilesPerTicket` consecutive tiles per draw (one address takes
+    // about 10^8 atomics per second, which cheap tiles -- one sample per pixel -- would exceed).  A wave's first
+    // ticket is its own number (the host starts the cursor at the number of waves); the next ticket is drawn
+    // when a ticket's first tile starts and only read after its last tile, so the atomic's round trip overlaps
+    // the work.
+    int nextTicket = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    int tile = 0, tileEnd = 0;
     for (;;) {
-        int tile = 0;
-        if (lane == 0) tile = atomicAdd(P.tileCursor, 1);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= P.numTiles) break;  // every wave reaches this: the cursor only grows
+        if (tile >= tileEnd) {
+            const int ticket = __builtin_amdgcn_readfirstlane(nextTicket);
+            tile = ticket * P.tilesPerTicket;
+            if (tile >= P.numTiles) break;  // every wave reaches this: the cursor only grows
+            tileEnd = min(tile + P.tilesPerTicket, P.numTiles);
+            if (lane == 0) nextTicket = atomicAdd(P.tileCursor, 1);
+        }
         const int ty = tile / P.tilesX, tx = tile - ty * P.tilesX;
         const int ix = tx * kTile + lx;
         const int by = ty * kTile + ly;  // row inside the band
@@ -530,7 +556,14 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 startSample(0);
             }
 
+#ifdef GRAFT_STAMPS
+            const unsigned long long stampLoop0 = clock64();
+            const bool loopLeader = lane == (int)__builtin_ctzll(__ballot(1));
+#endif
             while (mode != M_DONE) {
+#ifdef GRAFT_STAMPS
+                const unsigned long long stamp0 = clock64();
+#endif
                 Hit h;
                 int avoidShape = -1;
                 const unsigned char *avoidRow = nullptr;
@@ -546,8 +579,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     const bool tame = s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001;
                     if (tame && (SCREEN == 1 || s1 < 1e5)) {
                         const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
-                        if (SCREEN == 2) closestHitGrouped<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
-                        else closestHitScreened<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
+                        if (SCREEN == 2) closestHitGrouped<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
+                        else closestHitScreened<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
                     } else {  // exact loop over the doubles in global memory
                         closestHit<AVOID, false>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
                     }
@@ -556,6 +589,13 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 }
                 rayCount++;
                 testCount += (unsigned)P.numShapes - avoided;
+#ifdef GRAFT_STAMPS
+                const unsigned long long stamp1 = clock64();
+                if (lane == (int)__builtin_ctzll(__ballot(1))) {  // one lane of those in this trip books the time
+                    stampHit += stamp1 - stamp0;
+                    stampRounds++;
+                }
+#endif
 
                 bool finalize = false, unwind = false;
                 double v[3] = {0, 0, 0};
@@ -574,7 +614,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         loc[0] = h.x; loc[1] = h.y; loc[2] = h.z;
                         din[0] = d[0]; din[1] = d[1]; din[2] = d[2];
                         nrm[0] = nrm[1] = nrm[2] = 0;
-                        const double *g = (LDSGEOM && SCREEN == 0) ? (const double *)ldsGeom : P.geom;
+                        const double *g = (LDSGEOM && SCREEN == 0) ? (const double *)ldsGeom
+                                          : EXACTLDS ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
                         if (h.kind == GRAFT_SPHERE) {  // shapes.c:69-71
                             const double *c = g + 4 * (size_t)h.slot;
                             unit3(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
@@ -679,6 +720,9 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     else mode = M_DONE;
                 }
             }
+#ifdef GRAFT_STAMPS
+            if (loopLeader) stampLoop += clock64() - stampLoop0;
+#endif
             if (P.aliasing) {  // mainTracing.c:422-423: counter == numPasses^2
                 const double n = (double)nSamples;
                 acc[0] = acc[0] / n; acc[1] = acc[1] / n; acc[2] = acc[2] / n;
@@ -696,15 +740,28 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             }
             if (P.hitIndex) P.hitIndex[p] = firstIdx;
         }
+        ++tile;
     }
     if (P.counters) {
         for (int off = 32; off > 0; off >>= 1) {
             rayCount += __shfl_down(rayCount, off);
             testCount += __shfl_down(testCount, off);
+#ifdef GRAFT_STAMPS
+            stampHit += __shfl_down(stampHit, off);
+            stampRounds += __shfl_down(stampRounds, off);
+            stampLoop += __shfl_down(stampLoop, off);
+#endif
         }
         if (lane == 0) {
             atomicAdd(P.counters, rayCount);
             atomicAdd(P.counters + 1, testCount);
+#ifdef GRAFT_STAMPS
+            atomicAdd(P.counters + 2, (unsigned long long)(clock64() - stampBegin));
+            atomicAdd(P.counters + 3, stampHit);
+            atomicAdd(P.counters + 4, stampRounds);
+            atomicAdd(P.counters + 5, 1ull);
+            atomicAdd(P.counters + 6, stampLoop);
+#endif
         }
     }
 }
@@ -744,13 +801,16 @@ int fail(int code, const char *fmt, ...) {
 typedef void (*TraceFn)(const TraceParams);
 
 template <int A>
-TraceFn pickKernelA(bool lds, int screen) {
-    if (lds) return screen == 2 ? traceKernel<A, true, 2> : screen == 1 ? traceKernel<A, true, 1> : traceKernel<A, true, 0>;
-    return screen == 2 ? traceKernel<A, false, 2> : screen == 1 ? traceKernel<A, false, 1> : traceKernel<A, false, 0>;
+TraceFn pickKernelA(bool lds, int screen, bool exactLds) {
+    if (!lds) return screen == 2 ? traceKernel<A, false, 2, false> : screen == 1 ? traceKernel<A, false, 1, false> : traceKernel<A, false, 0, false>;
+    if (screen == 0) return traceKernel<A, true, 0, false>;
+    if (screen == 1) return exactLds ? traceKernel<A, true, 1, true> : traceKernel<A, true, 1, false>;
+    return exactLds ? traceKernel<A, true, 2, true> : traceKernel<A, true, 2, false>;
 }
 
-TraceFn pickKernel(int avoidMode, bool lds, int screen) {
-    return avoidMode == 0 ? pickKernelA<0>(lds, screen) : avoidMode == 1 ? pickKernelA<1>(lds, screen) : pickKernelA<2>(lds, screen);
+TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds) {
+    return avoidMode == 0 ? pickKernelA<0>(lds, screen, exactLds)
+         : avoidMode == 1 ? pickKernelA<1>(lds, screen, exactLds) : pickKernelA<2>(lds, screen, exactLds);
 }
 
 // Single-precision screen table.  Per sphere: (float)cx, (float)cy, (float)cz and rho >= r*r + the sphere's share
@@ -892,8 +952,10 @@ struct GraftJob {
     int avoidMode;
     int screen;   // 0 = exact only, 1 = single-precision screen per sphere, 2 = two-level (grouped) screen
     bool lds;
+    bool exactLds;  // exact doubles staged in LDS behind the screen table
     size_t ldsBytes;
     int block;
+    int blocksPerCU;  // resident workgroups per CU (occupancy query at the first trace), 0 = not asked yet
     void *arena;  // one device allocation holding every table
 };
 
@@ -922,8 +984,9 @@ GRAFT_API int graftInit(int device) {
     HIP_TRY(hipStreamCreateWithFlags(&gStream, hipStreamNonBlocking));
     for (int a = 0; a < 3; ++a)
         for (int f = 0; f < 3; ++f)
-            HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+            for (int x = 0; x < 2; ++x)
+                HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f, x != 0),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     gDevice = device;
     return GRAFT_OK;
 }
@@ -1127,10 +1190,16 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     P.tileCursor = (int *)(base + oCursor);
 
     job->avoidMode = avoidMode;
+    job->blocksPerCU = 0;
     job->screen = screen;
-    job->ldsBytes = screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)P.geomDoubles;
-    job->lds = job->ldsBytes <= kLdsMax;
-    job->block = (job->lds && job->ldsBytes > kLdsSmall) ? kLargeBlock : kSmallBlock;
+    const size_t tableBytes = screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)P.geomDoubles;
+    const size_t exactBytes = sizeof(double) * (size_t)P.geomDoubles;
+    job->lds = tableBytes <= kLdsMax;
+    job->exactLds = job->lds && screen && ((tableBytes + 31) & ~(size_t)31) + exactBytes <= kLdsMax;
+    P.exactLdsOffset = (int)((tableBytes + 31) & ~(size_t)31);
+    job->ldsBytes = !job->lds ? 0 : job->exactLds ? P.exactLdsOffset + exactBytes : tableBytes;
+    // workgroup size: as many workgroups per CU as the LDS footprint allows, 16 waves per CU in every case
+    job->block = job->ldsBytes <= kLdsSmall ? kSmallBlock : job->ldsBytes <= 2 * kLdsSmall ? 2 * kSmallBlock : kLargeBlock;
     *jobOut = job;
     return GRAFT_OK;
 }
@@ -1158,13 +1227,25 @@ GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void
     if (tiles > 0x7fff0000LL) return fail(GRAFT_ERR_ARG, "graftJobTrace: %lld tiles in one launch", tiles);
     P.numTiles = (int)tiles;
     const int wavesPerBlock = job->block / 64;
-    const int blocksPerCU = job->block == kLargeBlock ? 1 : 4;
+    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds);
+    if (job->blocksPerCU == 0) {  // persistent grid: as many workgroups as the kernel's registers and LDS let a CU hold
+        int perCU = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)fn, job->block, job->ldsBytes));
+        job->blocksPerCU = perCU < 1 ? 1 : perCU;
+    }
+    const int blocksPerCU = job->blocksPerCU;
     long long wantBlocks = (tiles + wavesPerBlock - 1) / wavesPerBlock;
     long long maxBlocks = (long long)gNumCU * blocksPerCU;
     const int grid = (int)(wantBlocks < maxBlocks ? wantBlocks : maxBlocks);
-    HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int), s));
-    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(job->block), job->lds ? job->ldsBytes : 0, s, P);
+    // cheap tiles (few samples per pixel) are drawn several at a time, but never so many that a wave gets fewer
+    // than 8 draws (load balance at the end of the launch)
+    const int samples = P.aliasing ? P.numPasses * P.numPasses : 1;
+    long long perTicket = 16 / samples < 1 ? 1 : (16 / samples > 4 ? 4 : 16 / samples);
+    const long long waves = (long long)grid * wavesPerBlock;
+    if (perTicket * waves * 8 > tiles) perTicket = tiles / (waves * 8) < 1 ? 1 : tiles / (waves * 8);
+    P.tilesPerTicket = (int)perTicket;
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)P.tileCursor, grid * wavesPerBlock, 1, s));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(job->block), job->ldsBytes, s, P);
     HIP_TRY(hipGetLastError());
     return GRAFT_OK;
 }
