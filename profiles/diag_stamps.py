@@ -13,7 +13,7 @@ raytracing_amd.init(0)
 rt = scenes.workload(name, None, height)
 job = rt.create_job()
 frame = torch.empty((job.nRows, job.nCols, 4), dtype=torch.float32, device="cuda")
-cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+cnt = torch.zeros(12, dtype=torch.int64, device="cuda")
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 for _ in range(2):
     cnt.zero_()
@@ -28,3 +28,4 @@ print("%s: waves %d, tiles %d, wave-rounds %d (%.1f lanes busy per round), cycle
       % (name, waves, tiles, rounds, rays / max(rounds, 1), total / max(waves, 1), 100.0 * hit / total,
          100.0 * (loop - hit) / total, 100.0 * (total - loop) / total, hit / max(rounds, 1), (loop - hit) / max(rounds, 1),
          (total - loop) / tiles))
+print("   per wave-round: %.1f groups whose members were screened, %.1f exact sphere tests" % (c[7] / max(rounds, 1), c[8] / max(rounds, 1)))

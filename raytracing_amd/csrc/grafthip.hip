@@ -365,6 +365,8 @@ __device__ __forceinline__ void closestHitScreened(const TraceParams &P, double 
     }
 }
 
+__device__ __forceinline__ int lane64() { return (int)(threadIdx.x & 63); }
+
 // screening values of the four spheres of one table block
 __device__ __forceinline__ void screenBlock(const float4v c0, const float4v c1, const float4v c2, const float4v c3,
                                             float sxf, float syf, float szf, float dxf, float dyf, float dzf,
@@ -383,8 +385,8 @@ __device__ __forceinline__ void screenBlock(const float4v c0, const float4v c1, 
 #endif
 }
 
-// Two-level screen for sphere-only scenes: spheres are sorted along a space-filling curve on the host and cut
-// into groups of 8; each group has a bounding ball (centre g, radius R >= |c_k - g| + r_k for its members, plus a
+// Two-level screen for sphere-only scenes: the host cuts the spheres into spatially compact groups of 8 (leaves of
+// a k-d tree); each group has a bounding ball (centre g, radius R >= |c_k - g| + r_k for its members, plus a
 // margin of 0.1).  A ray whose screening value for the bounding ball is below its threshold misses the ball by
 // more than the margin, hence (distance to a line is 1-Lipschitz) misses every member's sphere by more than the
 // margin, hence every member's double-precision discriminant in the reference is negative: the whole group is
@@ -421,6 +423,9 @@ __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double s
                     bool skip = shape < 0;
                     if (AVOID == 1) skip = skip || shape == avoidShape;
                     if (AVOID == 2) skip = skip || (avoidRow && shape >= 0 && avoidRow[shape]);
+#ifdef GRAFT_STAMPS
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
+#endif
                     if (!skip) exactSphere(geom, shape, shape, sx, sy, sz, dx, dy, dz, minDist, h);
                 }
             }
@@ -435,6 +440,9 @@ __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double s
             for (int u = 0; u < 4; ++u) {
                 const float eu = u == 0 ? e0 : u == 1 ? e1 : u == 2 ? e2 : e3;
                 if (!(eu < negThreshold)) {
+#ifdef GRAFT_STAMPS
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
+#endif
                     const float4v *mb = members + (size_t)(j + u) * 8;
                     members4(mb, (j + u) * 8);
                     members4(mb + 4, (j + u) * 8 + 4);
@@ -896,18 +904,37 @@ bool packGroupedTable(const std::vector<double> &sph, std::vector<float> &out, s
         if (!(fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + r < kGroupScale)) return false;  // also rejects NaN
         for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], c[a]); hi[a] = fmax(hi[a], c[a]); }
     }
-    // Morton order of the centres (10 bits per axis), ties by index
+    // groups = leaves of a k-d tree: split the longest axis of the centres' bounding box at the median (left part a
+    // multiple of the group size) until at most kGroup spheres remain; ties by index, so the result is deterministic
     std::vector<std::pair<unsigned, int>> order(n);
-    for (int k = 0; k < n; ++k) {
-        unsigned code = 0;
-        for (int a = 0; a < 3; ++a) {
-            const double span = hi[a] - lo[a];
-            unsigned q = span > 0 ? (unsigned)fmin(1023.0, (sph[4 * (size_t)k + a] - lo[a]) / span * 1024.0) : 0u;
-            for (int b = 0; b < 10; ++b) code |= ((q >> b) & 1u) << (3 * b + a);
+    {
+        std::vector<int> idx(n);
+        for (int k = 0; k < n; ++k) idx[k] = k;
+        std::vector<std::pair<int, int>> todo{{0, n}};
+        while (!todo.empty()) {
+            const std::pair<int, int> seg = todo.back();
+            todo.pop_back();
+            const int count = seg.second - seg.first;
+            if (count <= kGroup) continue;
+            double blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int i = seg.first; i < seg.second; ++i)
+                for (int a = 0; a < 3; ++a) {
+                    blo[a] = fmin(blo[a], sph[4 * (size_t)idx[i] + a]);
+                    bhi[a] = fmax(bhi[a], sph[4 * (size_t)idx[i] + a]);
+                }
+            int axis = 0;
+            for (int a = 1; a < 3; ++a)
+                if (bhi[a] - blo[a] > bhi[axis] - blo[axis]) axis = a;
+            const int half = (count / 2 + kGroup - 1) / kGroup * kGroup;
+            std::sort(idx.begin() + seg.first, idx.begin() + seg.second, [&](int x, int y) {
+                const double cx = sph[4 * (size_t)x + axis], cy = sph[4 * (size_t)y + axis];
+                return cx < cy || (cx == cy && x < y);
+            });
+            todo.push_back({seg.first, seg.first + half});
+            todo.push_back({seg.first + half, seg.second});
         }
-        order[k] = {code, k};
+        for (int k = 0; k < n; ++k) order[k] = {0u, idx[k]};
     }
-    std::sort(order.begin(), order.end());
     const int nGroups = (n + kGroup - 1) / kGroup;
     groupEntries = (nGroups + 7) / 8 * 8;
     memberBase = groupEntries + 8;
@@ -916,9 +943,23 @@ bool packGroupedTable(const std::vector<double> &sph, std::vector<float> &out, s
     for (int i = 0; i < memberBase; ++i) putEntry(out.data() + 16 * (i / 4), i % 4, 0.0f, 0.0f, 0.0f, -INFINITY);
     for (int gI = 0; gI < nGroups; ++gI) {
         const int first = gI * kGroup, last = std::min(n, first + kGroup);
+        // centre of the bounding ball: start at the centroid and walk towards the farthest sphere with shrinking
+        // steps (Badoiu-Clarkson); any centre is valid, the radius below is what makes the ball enclose the members
         double g[3] = {0, 0, 0};
         for (int m = first; m < last; ++m)
             for (int a = 0; a < 3; ++a) g[a] += sph[4 * (size_t)order[m].second + a] / (last - first);
+        for (int it = 0; it < 64; ++it) {
+            int far = first;
+            double farDist = -1;
+            for (int m = first; m < last; ++m) {
+                const double *c = &sph[4 * (size_t)order[m].second];
+                const double dx = c[0] - g[0], dy = c[1] - g[1], dz = c[2] - g[2];
+                const double dd = sqrt(dx * dx + dy * dy + dz * dz) + sqrt(c[3]);
+                if (dd > farDist) { farDist = dd; far = m; }
+            }
+            const double *c = &sph[4 * (size_t)order[far].second];
+            for (int a = 0; a < 3; ++a) g[a] += (c[a] - g[a]) / (it + 2);
+        }
         double R = 0;
         for (int m = first; m < last; ++m) {
             const double *c = &sph[4 * (size_t)order[m].second];
