@@ -67,9 +67,11 @@ def run_case(name):
         elif kind == "clear":
             R.clear_scene()
         elif kind == "sphere":
-            R.add_sphere(op[1], op[2], op[3], op[4], op[5])
+            R.add_sphere(op[1], op[2], op[3], op[4], op[5], *(op[6:8] if len(op) > 6 else (1.0, 0.0)))
         elif kind == "plane":
-            R.add_plane(op[1], op[2], op[3], op[4], op[5])
+            R.add_plane(op[1], op[2], op[3], op[4], op[5], *(op[6:8] if len(op) > 6 else (1.0, 0.0)))
+        elif kind == "material":
+            R.set_material(op[1], op[2], op[3], op[4], op[5])
         elif kind == "light":
             R.add_light(op[1], op[2], list(op[3]))
         elif kind == "camera":

@@ -145,7 +145,7 @@ def render(st, row0=0, n_rows=None, threads=1, want_rgb=True, want_index=False, 
                              index.ctypes.data_as(ctypes.c_void_p) if want_index else None,
                              cnt.ctypes.data_as(ctypes.c_void_p) if want_counters else None)
     if rc != 0:
-        raise ValueError("oracle refuses the scene (transparent shape)")
+        raise ValueError("oracle_render failed (%d)" % rc)
     out = dict(rgb=rgb, index=index, cols=pr.cols, rows=pr.rows)
     if want_counters:
         out["counters"] = tuple(int(c) for c in cnt)

@@ -55,6 +55,7 @@ class Reference:
         L.ref_add_plane.argtypes = [_dp, _dp, ctypes.c_double, _dp, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double]
         L.ref_add_light.argtypes = [_dp, _dp, _ip, ctypes.c_int]
+        L.ref_set_material.argtypes = [ctypes.c_int] + [ctypes.c_double] * 4
         L.ref_scene_initialize.argtypes = [_dp, ctypes.c_double, ctypes.c_double]
         L.ref_rotate_view.argtypes = [ctypes.c_double, _dp]
         L.ref_set_background.argtypes = [_dp]
@@ -89,6 +90,9 @@ class Reference:
         r = self.lib.ref_add_light(_d3(color), _d3(loc), arr, len(avoid))
         assert r >= 0, "reference light array full"
         return r
+
+    def set_material(self, k, reflectivity, ambient, refr_index, transparency):
+        self.lib.ref_set_material(k, reflectivity, ambient, refr_index, transparency)
 
     def scene_initialize(self, target=(0, 0, 0), to_screen=256.0, to_cam=1000.0):
         self.lib.ref_scene_initialize(_d3(target), to_screen, to_cam)

@@ -118,6 +118,11 @@ int ref_add_light(double color[3], double loc[3], const int32_t *avoidIdx, int n
     numLights = ++lightsLive;
     return lightsLive - 1;
 }
+/* overwrite the four material scalars of shapes[k] (shapes.c:20-23) */
+void ref_set_material(int k, double reflectivity, double ambient, double refrIndex, double transparency) {
+    shapes[k]->reflectivity = reflectivity; shapes[k]->ambientLight = ambient;
+    shapes[k]->refrIndex = refrIndex; shapes[k]->transparency = transparency;
+}
 void ref_scene_initialize(double tgt[3], double toScreen, double toCam) { sceneInitialize(tgt, toScreen, toCam); }
 void ref_rotate_view(double theta, double axis[3]) { rotateView(theta, axis); }
 

@@ -18,7 +18,8 @@
  *   - shapes carry a kind tag instead of function pointers, avoid lists hold indices instead of pointers;
  *   - mainTracing.c:323 (a copy out of an uninitialised array over the surface colour, deleted by the
  *     optimiser in the reference's own `clang -O3` build) is a no-op here;
- *   - transparency > 0 (refraction/fresnel, mainTracing.c:232-294) is not restated: oracle_render refuses it.
+ *   - refraction() scales its position argument in place (mainTracing.c:258), which in the reference
+ *     clobbers shootRay's intersectLoc after its last use; here the scaled copy is local (same results).
  */
 #include <math.h>
 #include <pthread.h>
@@ -172,7 +173,8 @@ static int closestHit(const OracleJob *J, const double s[3], const double d[3], 
     return best;
 }
 
-static int shoot(const OracleJob *J, const double s[3], const double d[3], double out[3], int depth, Counters *C);
+static int shoot(const OracleJob *J, const double s[3], const double d[3], double out[3], int depth,
+                 int shouldReflect, Counters *C);
 
 /* mainTracing.c:196-229: the last light that is not shadowed overwrites the result */
 static void diffuse(const OracleJob *J, const double loc[3], const double normal[3], const double surf[3],
@@ -206,9 +208,67 @@ static void diffuse(const OracleJob *J, const double loc[3], const double normal
     }
 }
 
+/* mainTracing.c:232-270, bug for bug: the POSITION s (not the direction d) is scaled by eta and used both in
+ * the refracted direction and as the origin of the refracted ray; when the ray leaves the shape
+ * (d.normal >= 0) the child may not reflect. */
+static void refract(const OracleJob *J, double refrIndex, const double hit[3], const double d[3],
+                    const double normal[3], double out[3], int depth, Counters *C) {
+    int childReflects = 1;
+    double s[3], n[3], dir[3];
+    v3copy(hit, s);
+    double cosD = v3dot(d, normal);
+    if (cosD < -1) cosD = -1;
+    if (cosD > 1) cosD = 1;
+    double etaD = 1, etaN = refrIndex;
+    v3copy(normal, n);
+    if (cosD < 0) {
+        cosD = -cosD;
+    } else {
+        etaD = etaN;
+        etaN = 1;
+        v3scale(-1, n, n);
+        childReflects = 0;
+    }
+    double eta = etaD / etaN;
+    double k = 1 - eta * eta * (1 - cosD * cosD);
+    if (k < 0) {
+        v3copy(d, dir);
+    } else {
+        v3scale(eta, s, s);
+        v3scale(eta * cosD - sqrt(k), n, n);
+        v3add(s, n, dir);
+    }
+    v3unit(dir, dir);
+    double tiny[3], origin[3], child[3] = {0, 0, 0};
+    v3scale(.000001, dir, tiny);
+    v3add(s, tiny, origin);
+    if (shoot(J, origin, dir, child, depth + 1, childReflects, C) >= 0) v3copy(child, out);
+}
+
+/* mainTracing.c:273-294, bug for bug: the indices live in float, the result is truncated to int (so the
+ * weight is 0 unless it is exactly 1) */
+static int fresnelWeight(double refrIndex, const double normal[3], const double d[3]) {
+    double cosD = v3dot(normal, d);
+    if (cosD < -1) cosD = -1;
+    if (cosD > 1) cosD = 1;
+    float etaD = 1, etaN = refrIndex;
+    if (cosD > 0) {
+        etaD = etaN;
+        etaN = 1;
+    }
+    float sinN = etaD / etaN * sqrt((1 - cosD * cosD) < 0 ? 0 : (1 - cosD * cosD));
+    if (sinN >= 1) return 1;
+    double cosN = sqrt((1 - sinN * sinN) < 0 ? 0 : (1 - sinN * sinN));
+    cosD = fabs(cosD);
+    double Rs = ((etaN * cosD) - (etaD * cosN)) / ((etaN * cosD) + (etaD * cosN));
+    double Rp = ((etaD * cosD) - (etaN * cosN)) / ((etaD * cosD) + (etaN * cosN));
+    return (Rs * Rs + Rp * Rp) / 2;
+}
+
 /* mainTracing.c:300-372 (reflection(): :180-193).  Returns like the reference: -2 at the depth cap, 0 on a
  * miss, otherwise the closest shape's index. */
-static int shoot(const OracleJob *J, const double s[3], const double d[3], double out[3], int depth, Counters *C) {
+static int shoot(const OracleJob *J, const double s[3], const double d[3], double out[3], int depth,
+                 int shouldReflect, Counters *C) {
     out[0] = out[1] = out[2] = 0;
     C->shoots++;
     if (depth >= J->maxDepth) return -2;
@@ -219,12 +279,12 @@ static int shoot(const OracleJob *J, const double s[3], const double d[3], doubl
         return 0;
     }
     const double *mat = J->material + 4 * (size_t)k;
-    double reflectivity = mat[0], ambient = mat[1];
+    double reflectivity = mat[0], ambient = mat[1], refrIndex = mat[2], transparency = mat[3];
     double rgb[3];
     surfaceColor(J, k, rgb);
 
     double mirror[3] = {0, 0, 0};
-    if (reflectivity > 0) { /* shouldReflect is 1 on every path that exists without transparency */
+    if (reflectivity > 0 && shouldReflect == 1) {
         double tint[3], white[3] = {1, 1, 1};
         v3sub(white, rgb, tint);
         v3scale(1 - .5, tint, tint);
@@ -236,7 +296,7 @@ static int shoot(const OracleJob *J, const double s[3], const double d[3], doubl
         v3unit(r, r);
         v3scale(.000001, r, tiny);
         v3add(loc, tiny, origin);
-        if (shoot(J, origin, r, child, depth + 1, C) >= 0) v3copy(child, mirror);
+        if (shoot(J, origin, r, child, depth + 1, 1, C) >= 0) v3copy(child, mirror);
         mirror[0] = tint[0] * mirror[0]; mirror[1] = tint[1] * mirror[1]; mirror[2] = tint[2] * mirror[2];
     }
 
@@ -244,10 +304,17 @@ static int shoot(const OracleJob *J, const double s[3], const double d[3], doubl
     diffuse(J, loc, normal, rgb, lighting, C);
 
     double refraction[3] = {0, 0, 0};
-    double transparency = mat[3];
+    if (transparency > 0) refract(J, refrIndex, loc, d, normal, refraction, depth, C);
+
     double wDiff = (1 - ambient) * (1 - reflectivity) * (1 - transparency);
-    double wRefl = (1 - ambient) * reflectivity;
-    double wRefr = 0;
+    double wRefl, wRefr;
+    if (transparency > 0) {
+        wRefl = fresnelWeight(refrIndex, normal, d);
+        wRefr = (1 - wRefl);
+    } else {
+        wRefl = (1 - ambient) * reflectivity;
+        wRefr = 0;
+    }
     double amb[3];
     v3scale(ambient, rgb, amb);
     v3scale(wRefl, mirror, mirror);
@@ -288,7 +355,7 @@ static void pixel(const OracleJob *J, int ix, int iy, double px[3], Counters *C)
             for (int l = 0; l < J->numPasses; l++) {
                 counter++;
                 primaryRay(J, i + J->subStepX * (k + 1), j + J->subStepY * (l + 1), origin, dir);
-                shoot(J, origin, dir, sample, 0, C);
+                shoot(J, origin, dir, sample, 0, 1, C);
                 v3add(rgb, sample, rgb);
             }
         }
@@ -296,7 +363,7 @@ static void pixel(const OracleJob *J, int ix, int iy, double px[3], Counters *C)
         px[0] = rgb[0] / counter; px[1] = rgb[1] / counter; px[2] = rgb[2] / counter;
     } else {
         primaryRay(J, i, j, origin, dir);
-        shoot(J, origin, dir, rgb, 0, C);
+        shoot(J, origin, dir, rgb, 0, 1, C);
         v3copy(rgb, px);
     }
 }
@@ -343,12 +410,10 @@ static void *chunkWorker(void *arg) {
  * (-1 = miss) of the anti-aliasing-off primary ray of each pixel (mainTracing.c:425-437 + :157).
  * counters (optional, 3 words) receive: closest-hit queries, ray-shape evaluations, shootRay calls made for rgb.
  * Work is handed to `threads` threads in pieces of 32 pixels of one row (pixels are independent).
- * Returns 0, or -1 if some shape is transparent (not restated).
+ * Returns 0.
  */
 int oracle_render(const OracleJob *J, int row0, int row1, int threads, double *rgb, int32_t *index,
                   uint64_t *counters) {
-    for (int k = 0; k < J->numShapes; ++k)
-        if (J->material[4 * (size_t)k + 3] > 0) return -1;
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
     volatile long next = 0;

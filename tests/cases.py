@@ -10,8 +10,9 @@ Operations:
   ("screen", width, height)                  screenWidth / screenHeight
   ("background", (r, g, b))
   ("clear",)                                 empty scene
-  ("sphere", center, radius, reflectivity, rgb, ambient)
-  ("plane", point, normal, reflectivity, rgb, ambient)
+  ("sphere", center, radius, reflectivity, rgb, ambient[, refrIndex, transparency])
+  ("plane", point, normal, reflectivity, rgb, ambient[, refrIndex, transparency])
+  ("material", shapeIndex, reflectivity, ambient, refrIndex, transparency)   overwrite a shape's material scalars
   ("light", color, loc, avoid-indices)
   ("camera", target, targetToScreen, screenToCam)      sceneInitialize
   ("rotate", theta, axis)                    rotateView
@@ -143,6 +144,37 @@ _add("parallel_planes_ortho", (64, 64), [("clear",), ("plane", (0, -100, 0), (0,
                                           ("camera", (0, 0, 0), 256, 1000), ("flags", O, OFF, 1, 4)])
 
 
+# -- transparency: refraction() and fresnel() of the reference, bugs included (mainTracing.c:232-294) --
+_add("glass_sphere4", (128, 128), [("default",), ("flags", P, OFF, 6, 4), ("material", 3, 1.0, 0.0, 1.5, 0.8)])
+_add("glass_two_depth10", (64, 64), [("default",), ("flags", P, OFF, 6, 10), ("material", 0, 0.5, 0.1, 1.33, 0.6),
+                                     ("material", 2, 0.0, 0.1, 1.1, 0.9)])
+_add("glass_plane_aa2", (64, 64), [("default",), ("flags", P, ON, 2, 4), ("material", 6, 0.5, 0.1, 1.2, 0.5),
+                                   ("material", 1, 1.0, 0.0, 0.8, 0.7)])
+_add("glass_ortho", (64, 64), [("default",), ("flags", O, OFF, 6, 4), ("material", 1, 0.3, 0.05, 1.5, 0.9),
+                               ("material", 4, 0.2, 0.1, 1.4, 0.3)])
+
+
+def _glass_mixed(seed):
+    rng = scenes.SplitMix64(0x61A55000 + seed)
+    ops = [("clear",), ("background", (0.1, 0.15, 0.2))]
+    for _ in range(10):
+        c = (rng.uniform(-250, 250), rng.uniform(-250, 250), rng.uniform(-100, 350))
+        glass = rng.uniform(0, 1) < 0.6
+        ops.append(("sphere", c, rng.uniform(30, 90), rng.uniform(0, 1) if rng.uniform(0, 1) < 0.6 else 0.0,
+                    (rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0, 1)), rng.uniform(0, 0.3),
+                    rng.uniform(0.7, 1.8), rng.uniform(0.2, 1.0) if glass else 0.0))
+    ops.append(("plane", (0, -300, 0), (0, 1, 0), 0.3, (.6, .6, .6), 0.1, 1.3, 0.4))
+    ops.append(("plane", (0, 0, 500), (0, 0, -1), 0.0, (.3, .5, .7), 0.1))
+    ops.append(("light", (1.2, 1.2, 1.2), (100, 250, -50), ()))
+    ops.append(("light", (.8, .8, .6), (-200, 200, 100), (0,)))
+    ops.append(("camera", (0, 0, 0), 256, 1000))
+    return ops
+
+
+for _seed in range(3):
+    _add("glass_mixed_%d" % _seed, (64, 64), _glass_mixed(_seed) + [("flags", P, OFF, 1, 5)])
+
+
 def apply_ops(ops, size=None):
     """Interpret a case against the product's host mirror; returns the RayTracer (nothing is traced)."""
     W, H = size if size else (512, 512)
@@ -171,11 +203,16 @@ def apply_ops(ops, size=None):
         elif kind == "clear":
             rt.shapes, rt.lights, rt.numShapes, rt.numLights = [], [], 0, 0
         elif kind == "sphere":
-            rt.sphereSetup(op[2], op[1], rt.numShapes, op[4], op[3], op[5], 1.0, 0.0)
+            refr, transp = op[6:8] if len(op) > 6 else (1.0, 0.0)
+            rt.sphereSetup(op[2], op[1], rt.numShapes, op[4], op[3], op[5], refr, transp)
             rt.numShapes += 1
         elif kind == "plane":
-            rt.planeSetup(op[2], op[1], rt.numShapes, op[4], op[3], op[5], 1.0, 0.0)
+            refr, transp = op[6:8] if len(op) > 6 else (1.0, 0.0)
+            rt.planeSetup(op[2], op[1], rt.numShapes, op[4], op[3], op[5], refr, transp)
             rt.numShapes += 1
+        elif kind == "material":
+            sh = rt.shapes[op[1]]
+            sh.reflectivity, sh.ambientLight, sh.refrIndex, sh.transparency = (float(v) for v in op[2:6])
         elif kind == "light":
             l = Light()
             lightInit(l, op[1], op[2])
