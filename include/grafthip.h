@@ -52,7 +52,7 @@ typedef struct GraftShape {
     double reflectivity; /* shapes.c:20 */
     double ambientLight; /* shapes.c:21 */
     double refrIndex;    /* shapes.c:22 */
-    double transparency; /* shapes.c:23; must be 0: refraction (mainTracing.c:232-294) is not implemented */
+    double transparency; /* shapes.c:23; > 0 switches on refraction()/fresnel() (mainTracing.c:232-294) */
 } GraftShape;
 
 /* One light: the reference's `light` (light.c:1-6); the `shape **avoid` list becomes a slice

@@ -93,6 +93,7 @@ extern __shared__ __attribute__((aligned(32))) double ldsGeom[];
 typedef double double4v __attribute__((ext_vector_type(4)));
 
 enum { M_RADIANCE = 0, M_SHADOW = 1, M_INDEX = 2, M_DONE = 3 };
+enum { F_MIRROR_PENDING = 1, F_HAS_REFRACTION = 2, F_REFRACTION_REFLECTS = 4 };
 
 struct Hit {
     int idx, slot, kind;
@@ -459,6 +460,68 @@ __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double s
     }
 }
 
+// fresnel() of the reference, mainTracing.c:273-294, bug for bug: the two indices live in `float`, sinN is
+// rounded to float, and the double result is truncated to int, so the weight is 0 unless it is exactly 1.
+// Float division and multiplication are done through double (exact product / correctly rounded quotient, then
+// one rounding to float), which equals the IEEE single-precision operation the CPU performs.
+__device__ __forceinline__ int fresnelWeight(double refrIndex, const double n[3], const double d[3]) {
+    double cosD = dot3(n[0], n[1], n[2], d[0], d[1], d[2]);
+    if (cosD < -1) cosD = -1;
+    if (cosD > 1) cosD = 1;
+    float etaD = 1, etaN = (float)refrIndex;
+    if (cosD > 0) {
+        etaD = etaN;
+        etaN = 1;
+    }
+    const float ratio = (float)((double)etaD / (double)etaN);
+    const double under = (1 - cosD * cosD) < 0 ? 0 : (1 - cosD * cosD);
+    const float sinN = (float)((double)ratio * sqrt(under));
+    if (sinN >= 1) return 1;
+    const float sq = (float)((double)sinN * (double)sinN);
+    const float rest = (float)(1.0 - (double)sq);
+    const double cosN = sqrt((double)(rest < 0 ? 0.0f : rest));
+    cosD = fabs(cosD);
+    const double Rs = (((double)etaN * cosD) - ((double)etaD * cosN)) / (((double)etaN * cosD) + ((double)etaD * cosN));
+    const double Rp = (((double)etaD * cosD) - ((double)etaN * cosN)) / (((double)etaD * cosD) + ((double)etaN * cosN));
+    return (int)((Rs * Rs + Rp * Rp) / 2);
+}
+
+// The ray refraction() shoots, mainTracing.c:232-265, bug for bug: the POSITION (not the direction) is scaled by
+// eta and serves both in the refracted direction and as the ray's origin.  Returns the child's shouldReflect.
+__device__ __forceinline__ int refractionRay(double refrIndex, const double loc[3], const double d[3],
+                                             const double nrm[3], double o[3], double dir[3]) {
+    int childReflects = 1;
+    double s[3] = {loc[0], loc[1], loc[2]};
+    double n[3] = {nrm[0], nrm[1], nrm[2]};
+    double cosD = dot3(d[0], d[1], d[2], nrm[0], nrm[1], nrm[2]);
+    if (cosD < -1) cosD = -1;
+    if (cosD > 1) cosD = 1;
+    double etaD = 1, etaN = refrIndex;
+    if (cosD < 0) {
+        cosD = -cosD;
+    } else {
+        etaD = etaN;
+        etaN = 1;
+        n[0] = -1 * n[0]; n[1] = -1 * n[1]; n[2] = -1 * n[2];
+        childReflects = 0;
+    }
+    const double eta = etaD / etaN;
+    const double k = 1 - eta * eta * (1 - cosD * cosD);
+    if (k < 0) {
+        dir[0] = d[0]; dir[1] = d[1]; dir[2] = d[2];
+    } else {
+        s[0] = eta * s[0]; s[1] = eta * s[1]; s[2] = eta * s[2];
+        const double f = eta * cosD - sqrt(k);
+        n[0] = f * n[0]; n[1] = f * n[1]; n[2] = f * n[2];
+        dir[0] = s[0] + n[0]; dir[1] = s[1] + n[1]; dir[2] = s[2] + n[2];
+    }
+    unit3(dir[0], dir[1], dir[2], dir[0], dir[1], dir[2]);
+    o[0] = s[0] + .000001 * dir[0];
+    o[1] = s[1] + .000001 * dir[1];
+    o[2] = s[2] + .000001 * dir[2];
+    return childReflects;
+}
+
 // ray through world offsets (xo, yo) of the screen plane: mainTracing.c:405-417 / :425-437
 __device__ __forceinline__ void primaryRay(const TraceParams &P, double xo, double yo, double o[3], double d[3]) {
     double col[3];
@@ -479,7 +542,9 @@ __device__ __forceinline__ unsigned quant8(double v) {
 // LDSGEOM: the table the hot loop reads (screen table, or the doubles when SCREEN == 0) is staged in LDS.
 // EXACTLDS (SCREEN > 0 only): the exact doubles are staged in LDS as well, behind the screen table; otherwise the
 // rare exact tests read them from global memory.
-template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS>
+// TRANSP: some shape is transparent: every shaded hit may spawn a refraction ray besides the mirror ray, so the
+// per-lane stack holds a tree walk (wider entries) instead of a chain.
+template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
     if (LDSGEOM) {
         if (SCREEN) {
@@ -533,7 +598,12 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             double o[3], d[3];                 // current ray
             double loc[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, din[3] = {0, 0, 0};  // shaded hit: point, normal, incoming dir
             double litW = 0;
-            double stk[kMaxDepth * 7];         // per level: P[3], tint[3], wRefl
+            // One entry per shaded hit whose children are still being traced: sum so far [3], tint [3], wRefl,
+            // and with TRANSP: wRefr, origin [3] and direction [3] of the refraction ray.  Flags: see F_*.
+            constexpr int kEntry = TRANSP ? 14 : 7;
+            double stk[kMaxDepth * kEntry];
+            unsigned char flags[kMaxDepth];
+            int rayReflects = 1;               // shouldReflect of the ray being traced (mainTracing.c:300)
 
             auto startSample = [&](int s) {
                 double xo = colI, yo = rowJ;
@@ -545,6 +615,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 primaryRay(P, xo, yo, o, d);
                 depth = 0;
                 sp = 0;
+                rayReflects = 1;  // launchRays passes shouldReflect = 1, mainTracing.c:391
                 mode = M_RADIANCE;
             };
             auto startShadow = [&](int light) {  // mainTracing.c:200-205
@@ -665,67 +736,121 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                             light[c] = litW * t;
                         }
                     }
+                    const bool mirror = m.reflectivity > 0 && rayReflects == 1;   // :330
+                    const bool glass = TRANSP && m.transparency > 0;               // :347, :355
                     const double wDiff = (1 - m.ambientLight) * (1 - m.reflectivity) * (1 - m.transparency);
-                    const double wRefl = (1 - m.ambientLight) * m.reflectivity;
+                    double wRefl = (1 - m.ambientLight) * m.reflectivity, wRefr = 0;
+                    if (glass) {
+                        wRefl = fresnelWeight(m.refrIndex, nrm, din);
+                        wRefr = (1 - wRefl);
+                    }
                     double part[3];
                     for (int c = 0; c < 3; ++c) {
                         const double amb = m.ambientLight * rgb[c];
                         const double lit = wDiff * light[c];
                         part[c] = lit + (amb + 0.0);
                     }
-                    if (m.reflectivity > 0) {
-                        double *lv = stk + 7 * sp;
+                    if (mirror || glass) {  // children to trace: push this level
+                        double *lv = stk + kEntry * sp;
+                        unsigned char fl = 0;
                         for (int c = 0; c < 3; ++c) {
-                            lv[c] = part[c];
                             const double t = (1 - .5) * (1.0 - rgb[c]);  // mainTracing.c:334-336
                             lv[3 + c] = rgb[c] + t;
                         }
                         lv[6] = wRefl;
-                        sp++;
-                        if (depth + 1 >= P.maxDepth) {  // the child returns -2 at once, mainTracing.c:305-306
-                            unwind = true;              // v stays 0
-                        } else {  // reflection(), mainTracing.c:180-190
-                            const double k2 = 2 * dot3(din[0], din[1], din[2], nrm[0], nrm[1], nrm[2]);
-                            double rx = din[0] - k2 * nrm[0], ry = din[1] - k2 * nrm[1], rz = din[2] - k2 * nrm[2];
-                            unit3(rx, ry, rz, rx, ry, rz);
-                            d[0] = rx; d[1] = ry; d[2] = rz;
-                            o[0] = loc[0] + .000001 * rx;
-                            o[1] = loc[1] + .000001 * ry;
-                            o[2] = loc[2] + .000001 * rz;
-                            depth++;
-                            mode = M_RADIANCE;
+                        if (glass) {
+                            if (TRANSP) {
+                                lv[7] = wRefr;
+                                if (refractionRay(m.refrIndex, loc, din, nrm, lv + 8, lv + 11)) fl |= F_REFRACTION_REFLECTS;
+                            }
+                            fl |= F_HAS_REFRACTION;
                         }
-                    } else {  // no mirror term: reflectionRGB stays {0,0,0}
+                        if (mirror) {
+                            for (int c = 0; c < 3; ++c) lv[c] = part[c];
+                            flags[sp++] = fl | F_MIRROR_PENDING;
+                            if (depth + 1 >= P.maxDepth) {  // the child returns -2 at once, mainTracing.c:305-306
+                                unwind = true;              // v stays 0
+                            } else {  // reflection(), mainTracing.c:180-190
+                                const double k2 = 2 * dot3(din[0], din[1], din[2], nrm[0], nrm[1], nrm[2]);
+                                double rx = din[0] - k2 * nrm[0], ry = din[1] - k2 * nrm[1], rz = din[2] - k2 * nrm[2];
+                                unit3(rx, ry, rz, rx, ry, rz);
+                                d[0] = rx; d[1] = ry; d[2] = rz;
+                                o[0] = loc[0] + .000001 * rx;
+                                o[1] = loc[1] + .000001 * ry;
+                                o[2] = loc[2] + .000001 * rz;
+                                depth++;
+                                rayReflects = 1;  // reflection() passes shouldReflect = 1, :181
+                                mode = M_RADIANCE;
+                            }
+                        } else {  // glass without a mirror ray: reflectionRGB stays {0,0,0}; go straight to refraction
+                            for (int c = 0; c < 3; ++c) lv[c] = (wRefl * 0.0) + part[c];
+                            flags[sp++] = fl;
+                            if (depth + 1 >= P.maxDepth) {
+                                unwind = true;  // v stays 0: the refraction child returns -2
+                            } else if (TRANSP) {
+                                o[0] = lv[8]; o[1] = lv[9]; o[2] = lv[10];
+                                d[0] = lv[11]; d[1] = lv[12]; d[2] = lv[13];
+                                rayReflects = (fl & F_REFRACTION_REFLECTS) ? 1 : 0;
+                                depth++;
+                                mode = M_RADIANCE;
+                            }
+                        }
+                    } else {  // no children: reflectionRGB and refractionRGB stay {0,0,0}
                         for (int c = 0; c < 3; ++c) {
                             const double mir = wRefl * 0.0;
                             double out = mir + part[c];
-                            out = (0.0 * 0.0) + out;
+                            out = (wRefr * 0.0) + out;
                             v[c] = out;
                         }
                         unwind = true;
                     }
                 }
 
-                if (unwind) {  // return through the pushed levels, innermost first (mainTracing.c:338, :363-369)
-                    while (sp > 0) {
-                        sp--;
-                        const double *lv = stk + 7 * sp;
-                        for (int c = 0; c < 3; ++c) {
-                            double mir = lv[3 + c] * v[c];
-                            mir = lv[6] * mir;
-                            double out = mir + lv[c];
-                            out = (0.0 * 0.0) + out;
-                            v[c] = out;
+                if (unwind) {  // a ray's value v is known: hand it up the tree, innermost first (:338, :363-369)
+                    bool launched = false;
+                    while (sp > 0 && !launched) {
+                        double *lv = stk + kEntry * (sp - 1);
+                        const unsigned char fl = flags[sp - 1];
+                        if (fl & F_MIRROR_PENDING) {  // v is the mirror child's value
+                            for (int c = 0; c < 3; ++c) {
+                                double mir = lv[3 + c] * v[c];
+                                mir = lv[6] * mir;
+                                lv[c] = mir + lv[c];
+                            }
+                            if (TRANSP && (fl & F_HAS_REFRACTION)) {  // now the refraction child, same depth
+                                flags[sp - 1] = fl & ~F_MIRROR_PENDING;
+                                if (sp >= P.maxDepth) {
+                                    v[0] = v[1] = v[2] = 0;  // it returns -2 at once
+                                } else {
+                                    o[0] = lv[8]; o[1] = lv[9]; o[2] = lv[10];
+                                    d[0] = lv[11]; d[1] = lv[12]; d[2] = lv[13];
+                                    rayReflects = (fl & F_REFRACTION_REFLECTS) ? 1 : 0;
+                                    depth = sp;
+                                    mode = M_RADIANCE;
+                                    launched = true;
+                                }
+                            } else {
+                                for (int c = 0; c < 3; ++c) v[c] = (0.0 * 0.0) + lv[c];
+                                sp--;
+                            }
+                        } else {  // v is the refraction child's value
+                            for (int c = 0; c < 3; ++c) {
+                                const double rf = (TRANSP ? lv[7] : 0.0) * v[c];
+                                v[c] = rf + lv[c];
+                            }
+                            sp--;
                         }
                     }
-                    if (P.aliasing) {  // mainTracing.c:419
-                        acc[0] = acc[0] + v[0]; acc[1] = acc[1] + v[1]; acc[2] = acc[2] + v[2];
-                    } else {
-                        acc[0] = v[0]; acc[1] = v[1]; acc[2] = v[2];
+                    if (!launched) {
+                        if (P.aliasing) {  // mainTracing.c:419
+                            acc[0] = acc[0] + v[0]; acc[1] = acc[1] + v[1]; acc[2] = acc[2] + v[2];
+                        } else {
+                            acc[0] = v[0]; acc[1] = v[1]; acc[2] = v[2];
+                        }
+                        sample++;
+                        if (sample < nSamples) startSample(sample);
+                        else mode = M_DONE;
                     }
-                    sample++;
-                    if (sample < nSamples) startSample(sample);
-                    else mode = M_DONE;
                 }
             }
 #ifdef GRAFT_STAMPS
@@ -810,13 +935,19 @@ typedef void (*TraceFn)(const TraceParams);
 
 template <int A>
 TraceFn pickKernelA(bool lds, int screen, bool exactLds) {
-    if (!lds) return screen == 2 ? traceKernel<A, false, 2, false> : screen == 1 ? traceKernel<A, false, 1, false> : traceKernel<A, false, 0, false>;
-    if (screen == 0) return traceKernel<A, true, 0, false>;
-    if (screen == 1) return exactLds ? traceKernel<A, true, 1, true> : traceKernel<A, true, 1, false>;
-    return exactLds ? traceKernel<A, true, 2, true> : traceKernel<A, true, 2, false>;
+    if (!lds) return screen == 2 ? traceKernel<A, false, 2, false, false> : screen == 1 ? traceKernel<A, false, 1, false, false> : traceKernel<A, false, 0, false, false>;
+    if (screen == 0) return traceKernel<A, true, 0, false, false>;
+    if (screen == 1) return exactLds ? traceKernel<A, true, 1, true, false> : traceKernel<A, true, 1, false, false>;
+    return exactLds ? traceKernel<A, true, 2, true, false> : traceKernel<A, true, 2, false, false>;
 }
 
-TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds) {
+// Scenes with a transparent shape run the tree-walk kernels, built only for the general avoid mode, screen
+// levels 0 and 1, and exact doubles in global memory (the jobs are normalised to that in graftJobCreate).
+TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp) {
+    if (transp) {
+        if (lds) return screen ? traceKernel<2, true, 1, false, true> : traceKernel<2, true, 0, false, true>;
+        return screen ? traceKernel<2, false, 1, false, true> : traceKernel<2, false, 0, false, true>;
+    }
     return avoidMode == 0 ? pickKernelA<0>(lds, screen, exactLds)
          : avoidMode == 1 ? pickKernelA<1>(lds, screen, exactLds) : pickKernelA<2>(lds, screen, exactLds);
 }
@@ -994,6 +1125,7 @@ struct GraftJob {
     int screen;   // 0 = exact only, 1 = single-precision screen per sphere, 2 = two-level (grouped) screen
     bool lds;
     bool exactLds;  // exact doubles staged in LDS behind the screen table
+    bool transp;    // some shape is transparent: tree-walk kernel
     size_t ldsBytes;
     int block;
     int blocksPerCU;  // resident workgroups per CU (occupancy query at the first trace), 0 = not asked yet
@@ -1026,8 +1158,9 @@ GRAFT_API int graftInit(int device) {
     for (int a = 0; a < 3; ++a)
         for (int f = 0; f < 3; ++f)
             for (int x = 0; x < 2; ++x)
-                HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f, x != 0),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+                for (int t = 0; t < 2; ++t)
+                    HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f, x != 0, t != 0),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     gDevice = device;
     return GRAFT_OK;
 }
@@ -1103,6 +1236,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     if (scene->maxDepth > kMaxDepth)
         return fail(GRAFT_ERR_UNSUPPORTED, "graftJobCreate: maxDepth %d > %d", scene->maxDepth, kMaxDepth);
 
+    bool transparent = false;
     std::vector<DevRun> runs;
     std::vector<DevMaterial> mats(nS);
     std::vector<double> sph, pln;
@@ -1110,8 +1244,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
         const GraftShape &s = scene->shapes[k];
         if (s.kind != GRAFT_SPHERE && s.kind != GRAFT_PLANE)
             return fail(GRAFT_ERR_ARG, "graftJobCreate: shape %d has kind %d", k, s.kind);
-        if (s.transparency > 0)
-            return fail(GRAFT_ERR_UNSUPPORTED, "graftJobCreate: shape %d is transparent; refraction is not implemented", k);
+        if (s.transparency > 0) transparent = true;
         int slot;
         if (s.kind == GRAFT_SPHERE) {
             slot = (int)(sph.size() / 4);
@@ -1175,9 +1308,10 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     const char *env = getenv("GRAFT_SCREEN");
     const int screenCap = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : 2;
     int screen = (screenCap >= 1 && !sph.empty()) ? 1 : 0;
+    if (transparent) avoidMode = 2;  // the tree-walk kernels exist for the general avoid mode only
     std::vector<float> tableF;
     std::vector<int> memberShape;
-    if (screen && screenCap >= 2 && pln.empty() &&
+    if (screen && screenCap >= 2 && pln.empty() && !transparent &&
         packGroupedTable(sph, tableF, memberShape, P.groupEntries, P.memberBase)) screen = 2;
     if (screen != 2) { P.groupEntries = 0; P.memberBase = 0; memberShape.clear(); }
     if (screen == 1) packScreenTable(sph, runs, tableF);
@@ -1236,7 +1370,8 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     const size_t tableBytes = screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)P.geomDoubles;
     const size_t exactBytes = sizeof(double) * (size_t)P.geomDoubles;
     job->lds = tableBytes <= kLdsMax;
-    job->exactLds = job->lds && screen && ((tableBytes + 31) & ~(size_t)31) + exactBytes <= kLdsMax;
+    job->transp = transparent;
+    job->exactLds = !transparent && job->lds && screen && ((tableBytes + 31) & ~(size_t)31) + exactBytes <= kLdsMax;
     P.exactLdsOffset = (int)((tableBytes + 31) & ~(size_t)31);
     job->ldsBytes = !job->lds ? 0 : job->exactLds ? P.exactLdsOffset + exactBytes : tableBytes;
     // workgroup size: as many workgroups per CU as the LDS footprint allows, 16 waves per CU in every case
@@ -1268,7 +1403,7 @@ GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void
     if (tiles > 0x7fff0000LL) return fail(GRAFT_ERR_ARG, "graftJobTrace: %lld tiles in one launch", tiles);
     P.numTiles = (int)tiles;
     const int wavesPerBlock = job->block / 64;
-    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds);
+    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp);
     if (job->blocksPerCU == 0) {  // persistent grid: as many workgroups as the kernel's registers and LDS let a CU hold
         int perCU = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)fn, job->block, job->ldsBytes));
