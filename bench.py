@@ -78,6 +78,50 @@ def cpu_baseline(rt, gpu_band, row0, n_rows, cores, budget_rows):
             "sample_matches_gpu": bool(exact)}
 
 
+def frame_512(dev):
+    """The metric's "512x512 frame time": the reference's start-up scene cut to one sphere + one light (1 spp) and
+    the full start-up scene (6x6 supersampling), as kernel time (HIP events) and, for the former, as one whole
+    launchRays-style call with host buffers (scene upload + trace + copy back over PCIe)."""
+    out = {}
+    stream = torch.cuda.current_stream()
+    for key, name in (("single_sphere", "single"), ("startup_scene_aa6", "default")):
+        rt, _ = build_workload(name)
+        job = rt.create_job()
+        buf = torch.empty((job.nRows, job.nCols, 4), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            job.trace(0, job.nRows, GRAFT_OUT_F32_RGBA, buf.data_ptr(), None, None, stream.cuda_stream)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        a.record()
+        for _ in range(reps):
+            job.trace(0, job.nRows, GRAFT_OUT_F32_RGBA, buf.data_ptr(), None, None, stream.cuda_stream)
+        b.record()
+        torch.cuda.synchronize()
+        out[key + "_kernel_ms"] = a.elapsed_time(b) / reps
+        job.close()
+        if name == "single":
+            rt.render_rows()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                rt.render_rows()
+            out[key + "_host_call_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+    return out
+
+
+def recorded_traffic(workload, frame):
+    """HBM bytes per launch measured offline with rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) on this same
+    command; kept under profiles/ because counters cannot be read from inside the process."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("workload") == workload and rec.get("frame") == frame:
+            return rec.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +133,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the frame the CPU baseline traces")
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-frame512", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,9 +217,11 @@ def main():
             "primary_Msamples_per_s": W * H * (rt.numPasses ** 2 if rt.aliasing else 1) / (elapsed / args.steps) / 1e6,
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU, "frac_nofma": achieved / PEAK_FP64_NOFMA,
-                         "traffic": None, "kernel": "traceKernel", "kernel_ms": kernel_ms,
+                         "traffic": recorded_traffic(args.workload, [W, H]), "kernel": "traceKernel", "kernel_ms": kernel_ms,
                          "tests_per_launch": local_tests, "flop_per_test": FLOP_PER_TEST},
         }
+        if world == 1 and not args.no_frame512:
+            out["frame_512"] = frame_512(dev)
         if world == 1 and not args.no_cpu:
             rows = args.cpu_rows
             if rows is None:  # aim at roughly 15 s of CPU work: ~1e8 tests/s per core

@@ -164,6 +164,11 @@ GRAFT_API int graftSynchronize(void);
 GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
                               void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost);
 
+/* Write a host frame (row iy = 0 is the BOTTOM row, as pixSetRGB's y: 000pixel.h:53-55) as a binary PPM (P6, top
+ * row first), quantising with q(v) = (uint8)(min(max(v,0),1)*255 + 0.5) where the format is not already 8 bit.
+ * For headless runs: the reference can only show its frame in a window (000pixel.h:31-39). */
+GRAFT_API int graftWritePPM(const char *path, const void *frameHost, int format, int nCols, int nRows);
+
 /* Bytes per pixel of a GRAFT_OUT_* format, 0 if unknown. */
 GRAFT_API size_t graftPixelBytes(int format);
 

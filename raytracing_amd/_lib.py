@@ -82,6 +82,7 @@ lib.graftJobTrace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctype
 lib.graftSynchronize.restype = ctypes.c_int
 lib.graftRenderRows.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTER(GraftView), ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+lib.graftWritePPM.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 lib.graftPixelBytes.argtypes = [ctypes.c_int]
 lib.graftPixelBytes.restype = ctypes.c_size_t
 lib.graftProbeSqrt.argtypes = [c_double_p, c_double_p, ctypes.c_size_t]

@@ -1176,6 +1176,32 @@ GRAFT_API void graftShutdown(void) {
 
 GRAFT_API const char *graftLastError(void) { return gError; }
 
+GRAFT_API int graftWritePPM(const char *path, const void *frameHost, int format, int nCols, int nRows) {
+    if (!path || !frameHost || nCols <= 0 || nRows <= 0 || graftPixelBytes(format) == 0)
+        return fail(GRAFT_ERR_ARG, "graftWritePPM: bad argument");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(GRAFT_ERR_ARG, "graftWritePPM: cannot open %s", path);
+    fprintf(f, "P6\n%d %d\n255\n", nCols, nRows);
+    std::vector<unsigned char> row(3 * (size_t)nCols);
+    auto q = [](double v) { return (unsigned char)((v < 0 ? 0 : (v > 1 ? 1 : (v == v ? v : 0))) * 255 + 0.5); };
+    for (int iy = nRows - 1; iy >= 0; --iy) {
+        for (int ix = 0; ix < nCols; ++ix) {
+            const size_t p = (size_t)iy * nCols + ix;
+            for (int c = 0; c < 3; ++c) {
+                if (format == GRAFT_OUT_F64_RGB) row[3 * ix + c] = q(((const double *)frameHost)[3 * p + c]);
+                else if (format == GRAFT_OUT_F32_RGBA) row[3 * ix + c] = q(((const float *)frameHost)[4 * p + c]);
+                else row[3 * ix + c] = ((const unsigned char *)frameHost)[4 * p + c];
+            }
+        }
+        if (fwrite(row.data(), 1, row.size(), f) != row.size()) {
+            fclose(f);
+            return fail(GRAFT_ERR_ARG, "graftWritePPM: short write to %s", path);
+        }
+    }
+    fclose(f);
+    return GRAFT_OK;
+}
+
 GRAFT_API size_t graftPixelBytes(int format) {
     switch (format) {
         case GRAFT_OUT_F64_RGB: return 24;

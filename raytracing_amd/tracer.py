@@ -40,6 +40,12 @@ def device_count():
     return max(n, 0)
 
 
+def write_ppm(path, frame, fmt=GRAFT_OUT_F64_RGB):
+    """Save a host frame ([rows][cols][channels], row 0 at the bottom as pixSetRGB counts) as a binary PPM."""
+    a = np.ascontiguousarray(frame)
+    check(lib.graftWritePPM(str(path).encode(), a.ctypes.data_as(ctypes.c_void_p), int(fmt), a.shape[1], a.shape[0]))
+
+
 # ---- shapes.c / light.c ---------------------------------------------------------------------------------
 
 class Shape:

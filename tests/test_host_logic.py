@@ -66,3 +66,25 @@ def test_band_rows_partition(rows, world):
     assert bands[0][0] == 0 and sum(n for _, n in bands) == rows
     for (a, n), (b, _) in zip(bands, bands[1:]):
         assert a + n == b and (n == 0 or a % 8 == 0)
+
+
+def test_write_ppm(tmp_path):
+    """Headless output: P6, top row first, the 8-bit quantiser of the RGB bar."""
+    from raytracing_amd import GRAFT_OUT_F32_RGBA, GRAFT_OUT_F64_RGB, GRAFT_OUT_U8_RGBA, write_ppm
+    rng = np.random.default_rng(3)
+    f64 = rng.uniform(-0.2, 1.3, (5, 7, 3))
+    f64[0, 0] = [np.nan, 0.5, 1.0]
+    want = (np.clip(np.nan_to_num(f64), 0, 1) * 255 + 0.5).astype(np.uint8)[::-1]
+    for fmt, frame in ((GRAFT_OUT_F64_RGB, f64),
+                       (GRAFT_OUT_F32_RGBA, np.concatenate([f64, np.ones((5, 7, 1))], 2).astype(np.float32)),
+                       (GRAFT_OUT_U8_RGBA, np.concatenate([want[::-1], np.full((5, 7, 1), 255, np.uint8)], 2))):
+        path = tmp_path / ("f%d.ppm" % fmt)
+        write_ppm(path, frame, fmt)
+        raw = open(path, "rb").read()
+        assert raw.startswith(b"P6\n7 5\n255\n")
+        got = np.frombuffer(raw[len(b"P6\n7 5\n255\n"):], dtype=np.uint8).reshape(5, 7, 3)
+        if fmt == GRAFT_OUT_F32_RGBA:
+            want32 = (np.clip(np.nan_to_num(frame[..., :3].astype(np.float64)), 0, 1) * 255 + 0.5).astype(np.uint8)[::-1]
+            assert np.array_equal(got, want32)
+        else:
+            assert np.array_equal(got, want)
