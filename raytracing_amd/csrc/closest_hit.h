@@ -1,0 +1,448 @@
+// closest_hit.h -- device functions of the path: vector helpers, exact sphere/plane tests, the single-precision
+// screens, Fresnel/refraction, ray generation (included by grafthip.hip only; compile with -ffp-contract=off).
+#pragma once
+
+#include "trace_types.h"
+
+namespace graft {
+
+// vector.c:57-64: the sum starts from 0.0
+__device__ __forceinline__ double dot3(double ax, double ay, double az, double bx, double by, double bz) {
+    double acc = 0.0;
+    acc += ax * bx;
+    acc += ay * by;
+    acc += az * bz;
+    return acc;
+}
+
+// vector.c:74-82: the output is left alone when the length is not positive
+__device__ __forceinline__ void unit3(double vx, double vy, double vz, double &ox, double &oy, double &oz) {
+    double mag = sqrt(dot3(vx, vy, vz, vx, vy, vz));
+    if (mag > 0) {
+        ox = vx / mag;
+        oy = vy / mag;
+        oz = vz / mag;
+    }
+}
+
+// mainTracing.c:104-114 with the denominator dir.dir hoisted (it only depends on dir)
+__device__ __forceinline__ void newPoint(const double start[3], const double dir[3], double den, double dist,
+                                         double out[3]) {
+    double scalar = sqrt(dist * dist / den);
+    if (dist < 0) scalar = -scalar;
+    out[0] = start[0] + scalar * dir[0];
+    out[1] = start[1] + scalar * dir[1];
+    out[2] = start[2] + scalar * dir[2];
+}
+
+// rayIntersectAvoid (mainTracing.c:128-153) over sphereIntersect (shapes.c:47-73) and planeIntersect
+// (shapes.c:83-96).  Candidate normals are not formed here: only the winner's is used (mainTracing.c:146).
+template <int AVOID, bool LDSGEOM>
+__device__ __forceinline__ void closestHit(const TraceParams &P, double sx, double sy, double sz, double dx,
+                                           double dy, double dz, int avoidShape,
+                                           const unsigned char *avoidRow, Hit &h) {
+    const double *geom = LDSGEOM ? (const double *)ldsGeom : P.geom;
+    double minDist = -1;
+    h.idx = -1;
+    h.slot = 0;
+    h.kind = 0;
+    h.x = h.y = h.z = 0;
+    for (int r = 0; r < P.numRuns; ++r) {
+        const DevRun run = P.runs[r];
+        if (run.kind == GRAFT_SPHERE) {
+            const double *sp = geom + 4 * (size_t)run.slot;
+#pragma unroll 4
+            for (int j = 0; j < run.count; ++j) {
+                const double4v c4 = *(const double4v *)(sp + 4 * j);
+                const double cx = c4.x, cy = c4.y, cz = c4.z, rr = c4.w;
+                const double vx = sx - cx, vy = sy - cy, vz = sz - cz;
+                // vecDot's leading "0.0 +" only turns a -0 result into +0; it cannot change b*b or v.v
+                const double b = vx * dx + vy * dy + vz * dz;
+                const double vv = vx * vx + vy * vy + vz * vz;
+                const double disc = b * b - (vv - rr);
+                bool candidate = !(disc < 0);
+                if (AVOID == 1) candidate = candidate && (run.firstShape + j != avoidShape);
+                if (AVOID == 2) candidate = candidate && !(avoidRow && avoidRow[run.firstShape + j]);
+                if (candidate) {
+                    const double q = sqrt(disc);
+                    const double bz = b + 0.0;  // restores the +0 of the reference's dot product
+                    const double tFar = -bz + q;
+                    const double tNear = -bz - q;
+                    const double t = tNear >= 0 ? tNear : tFar;
+                    if (!(t < 0)) {
+                        const double lx = sx + t * dx, ly = sy + t * dy, lz = sz + t * dz;
+                        const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
+                        const double dist = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+                        if (minDist == -1 || dist < minDist) {
+                            minDist = dist;
+                            h.idx = run.firstShape + j;
+                            h.slot = run.slot + j;
+                            h.kind = GRAFT_SPHERE;
+                            h.x = lx; h.y = ly; h.z = lz;
+                        }
+                    }
+                }
+            }
+        } else {
+            const double *pl = geom + 4 * (size_t)P.numSpheres + 6 * (size_t)run.slot;
+            for (int j = 0; j < run.count; ++j) {
+                const double px = pl[6 * j], py = pl[6 * j + 1], pz = pl[6 * j + 2];
+                const double nx = pl[6 * j + 3], ny = pl[6 * j + 4], nz = pl[6 * j + 5];
+                bool skip = false;
+                if (AVOID == 1) skip = (run.firstShape + j == avoidShape);
+                if (AVOID == 2) skip = avoidRow && avoidRow[run.firstShape + j];
+                const double d = dot3(px - sx, py - sy, pz - sz, nx, ny, nz) / dot3(dx, dy, dz, nx, ny, nz);
+                if (!skip && !(d < 0)) {
+                    const double lx = sx + d * dx, ly = sy + d * dy, lz = sz + d * dz;
+                    const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
+                    const double dist = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+                    if (minDist == -1 || dist < minDist) {
+                        minDist = dist;
+                        h.idx = run.firstShape + j;
+                        h.slot = run.slot + j;
+                        h.kind = GRAFT_PLANE;
+                        h.x = lx; h.y = ly; h.z = lz;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One exact sphere test + closest-hit update: sphereIntersect (shapes.c:47-73) and the body of the loop of
+// rayIntersectAvoid (mainTracing.c:139-149), for the sphere in geometry slot `slot` (shape index `shape`).
+__device__ __forceinline__ void exactSphere(const double *geom, int slot, int shape, double sx, double sy, double sz,
+                                            double dx, double dy, double dz, double &minDist, Hit &h) {
+    const double4v c4 = *(const double4v *)(geom + 4 * (size_t)slot);
+    const double vx = sx - c4.x, vy = sy - c4.y, vz = sz - c4.z;
+    const double b = vx * dx + vy * dy + vz * dz;
+    const double vv = vx * vx + vy * vy + vz * vz;
+    const double disc = b * b - (vv - c4.w);
+    if (!(disc < 0)) {
+        const double q = sqrt(disc);
+        const double bz = b + 0.0;
+        const double tFar = -bz + q;
+        const double tNear = -bz - q;
+        const double t = tNear >= 0 ? tNear : tFar;
+        if (!(t < 0)) {
+            const double lx = sx + t * dx, ly = sy + t * dy, lz = sz + t * dz;
+            const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
+            const double dist = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+            // "first in index order wins a tie" (mainTracing.c:143-144), written so that it also holds when
+            // spheres are visited out of index order (grouped screen); in index order the last clause never fires
+            if (minDist == -1 || dist < minDist || (dist == minDist && shape < h.idx)) {
+                minDist = dist;
+                h.idx = shape;
+                h.slot = slot;
+                h.kind = GRAFT_SPHERE;
+                h.x = lx; h.y = ly; h.z = lz;
+            }
+        }
+    }
+}
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+#ifndef GRAFT_SCREEN_PACKED
+#define GRAFT_SCREEN_PACKED 1
+#endif
+
+// Single-precision screening value of one sphere for one ray: an approximation of the discriminant
+// b*b - (v.v - r*r) of shapes.c:54 evaluated with fused multiply-adds on operands rounded to float, with the
+// sphere's share of the worst-case error already folded into rho (see packScreenTable).  A value below the
+// ray's threshold PROVES that the double-precision discriminant of the reference is negative.
+__device__ __forceinline__ float screen1(float cx, float cy, float cz, float rho, float sx, float sy, float sz,
+                                         float dx, float dy, float dz) {
+    const float vx = sx - cx, vy = sy - cy, vz = sz - cz;
+    float b = vx * dx;
+    b = __builtin_fmaf(vy, dy, b);
+    b = __builtin_fmaf(vz, dz, b);
+    float vv = vx * vx;
+    vv = __builtin_fmaf(vy, vy, vv);
+    vv = __builtin_fmaf(vz, vz, vv);
+    float t = rho - vv;
+    return __builtin_fmaf(b, b, t);
+}
+
+// the same for two spheres at once in packed single precision (v_pk_add/mul/fma_f32)
+__device__ __forceinline__ float2v screen2(float2v cx, float2v cy, float2v cz, float2v rho, float2v sx, float2v sy,
+                                           float2v sz, float2v dx, float2v dy, float2v dz) {
+    const float2v vx = sx - cx, vy = sy - cy, vz = sz - cz;
+    float2v b = vx * dx;
+    b = __builtin_elementwise_fma(vy, dy, b);
+    b = __builtin_elementwise_fma(vz, dz, b);
+    float2v vv = vx * vx;
+    vv = __builtin_elementwise_fma(vy, vy, vv);
+    vv = __builtin_elementwise_fma(vz, vz, vv);
+    const float2v t = rho - vv;
+    return __builtin_elementwise_fma(b, b, t);
+}
+
+// rayIntersectAvoid with a conservative single-precision screen in front of the exact test.  Every sphere is
+// still visited by every ray, in index order; the screen only skips spheres whose exact discriminant is
+// provably negative (a miss in shapes.c:55-57), so hit masks and hit points are bit-for-bit unchanged.
+// Error budget (u = 2^-24, A = |s|_1 + |c|_1, |d_i| <= 1): rounding s, c, d to float and evaluating in float
+// perturbs the discriminant by at most 24 u A^2 + 2.02 u rho <= 48 u |s|_1^2 + 48 u |c|_1^2 + 2.02 u rho; the
+// reference's own double rounding adds less than 2^-28 of that.  The ray carries 64 u |s|_1^2 (negThreshold),
+// the sphere carries 64 u |c|_1^2 + 2.2 u rho inside rho.  A ray whose coordinates are not finite, huge, or
+// whose direction is not inside the unit cube is not screened at all (the caller takes the exact loop), and
+// a sphere with such coordinates has rho = +inf and always passes.  With those two rules no screening value
+// is ever NaN, so four of them can be merged with max() and tested with one compare.
+template <int AVOID, bool LDSGEOM, bool EXACTLDS>
+__device__ __forceinline__ void closestHitScreened(const TraceParams &P, double sx, double sy, double sz, double dx,
+                                                   double dy, double dz, int avoidShape,
+                                                   const unsigned char *avoidRow, float negThreshold, Hit &h) {
+    const float4v *tableF = LDSGEOM ? (const float4v *)ldsGeom : (const float4v *)P.geomF;
+    const double *geom = EXACTLDS ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
+    double minDist = -1;
+    h.idx = -1;
+    h.slot = 0;
+    h.kind = 0;
+    h.x = h.y = h.z = 0;
+    const float sxf = (float)sx, syf = (float)sy, szf = (float)sz;
+    const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
+    auto visit = [&](int slot, int shape) {
+        bool skip = false;
+        if (AVOID == 1) skip = shape == avoidShape;
+        if (AVOID == 2) skip = avoidRow && avoidRow[shape];
+        if (!skip) exactSphere(geom, slot, shape, sx, sy, sz, dx, dy, dz, minDist, h);
+    };
+    for (int r = 0; r < P.numRuns; ++r) {
+        const DevRun run = P.runs[r];
+        if (run.kind == GRAFT_SPHERE) {
+            const float4v *sp = tableF + run.fslot;
+            // Four spheres per block; blocks are handled in pairs (A, B) so that each block's registers are
+            // refilled from LDS while the other block is being evaluated, without register copies.  Every run's
+            // part of the table holds a multiple of 8 entries and the table ends with 8 entries of padding.
+            auto block = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j) {
+                float e0, e1, e2, e3;
+#if GRAFT_SCREEN_PACKED
+                // block layout: {cx0 cx1 cy0 cy1} {cz0 cz1 rho0 rho1} {cx2 cx3 cy2 cy3} {cz2 cz3 rho2 rho3}
+                const float2v S0 = {sxf, sxf}, S1 = {syf, syf}, S2 = {szf, szf};
+                const float2v D0 = {dxf, dxf}, D1 = {dyf, dyf}, D2 = {dzf, dzf};
+                const float2v ea = screen2(c0.xy, c0.zw, c1.xy, c1.zw, S0, S1, S2, D0, D1, D2);
+                const float2v eb = screen2(c2.xy, c2.zw, c3.xy, c3.zw, S0, S1, S2, D0, D1, D2);
+                e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
+#else
+                e0 = screen1(c0.x, c0.y, c0.z, c0.w, sxf, syf, szf, dxf, dyf, dzf);
+                e1 = screen1(c1.x, c1.y, c1.z, c1.w, sxf, syf, szf, dxf, dyf, dzf);
+                e2 = screen1(c2.x, c2.y, c2.z, c2.w, sxf, syf, szf, dxf, dyf, dzf);
+                e3 = screen1(c3.x, c3.y, c3.z, c3.w, sxf, syf, szf, dxf, dyf, dzf);
+#endif
+                const float best = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
+                if (!(best < negThreshold)) {  // rare: some lane may hit one of the four
+                    const int k = run.count - j;  // live spheres from j on (the rest of the run's part is padding)
+                    if (k > 0 && !(e0 < negThreshold)) visit(run.slot + j, run.firstShape + j);
+                    if (k > 1 && !(e1 < negThreshold)) visit(run.slot + j + 1, run.firstShape + j + 1);
+                    if (k > 2 && !(e2 < negThreshold)) visit(run.slot + j + 2, run.firstShape + j + 2);
+                    if (k > 3 && !(e3 < negThreshold)) visit(run.slot + j + 3, run.firstShape + j + 3);
+                }
+            };
+            float4v a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
+            for (int j = 0; j < run.fcount; j += 8) {
+                const float4v b0 = sp[j + 4], b1 = sp[j + 5], b2 = sp[j + 6], b3 = sp[j + 7];
+                block(a0, a1, a2, a3, j);
+                a0 = sp[j + 8]; a1 = sp[j + 9]; a2 = sp[j + 10]; a3 = sp[j + 11];
+                block(b0, b1, b2, b3, j + 4);
+            }
+        } else {
+            const double *pl = geom + 4 * (size_t)P.numSpheres + 6 * (size_t)run.slot;
+            for (int j = 0; j < run.count; ++j) {
+                const double px = pl[6 * j], py = pl[6 * j + 1], pz = pl[6 * j + 2];
+                const double nx = pl[6 * j + 3], ny = pl[6 * j + 4], nz = pl[6 * j + 5];
+                bool skip = false;
+                if (AVOID == 1) skip = (run.firstShape + j == avoidShape);
+                if (AVOID == 2) skip = avoidRow && avoidRow[run.firstShape + j];
+                const double d = dot3(px - sx, py - sy, pz - sz, nx, ny, nz) / dot3(dx, dy, dz, nx, ny, nz);
+                if (!skip && !(d < 0)) {
+                    const double lx = sx + d * dx, ly = sy + d * dy, lz = sz + d * dz;
+                    const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
+                    const double dist = sqrt(dot3(ex, ey, ez, ex, ey, ez));
+                    if (minDist == -1 || dist < minDist) {
+                        minDist = dist;
+                        h.idx = run.firstShape + j;
+                        h.slot = run.slot + j;
+                        h.kind = GRAFT_PLANE;
+                        h.x = lx; h.y = ly; h.z = lz;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int lane64() { return (int)(threadIdx.x & 63); }
+
+// screening values of the four spheres of one table block
+__device__ __forceinline__ void screenBlock(const float4v c0, const float4v c1, const float4v c2, const float4v c3,
+                                            float sxf, float syf, float szf, float dxf, float dyf, float dzf,
+                                            float &e0, float &e1, float &e2, float &e3) {
+#if GRAFT_SCREEN_PACKED
+    const float2v S0 = {sxf, sxf}, S1 = {syf, syf}, S2 = {szf, szf};
+    const float2v D0 = {dxf, dxf}, D1 = {dyf, dyf}, D2 = {dzf, dzf};
+    const float2v ea = screen2(c0.xy, c0.zw, c1.xy, c1.zw, S0, S1, S2, D0, D1, D2);
+    const float2v eb = screen2(c2.xy, c2.zw, c3.xy, c3.zw, S0, S1, S2, D0, D1, D2);
+    e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
+#else
+    e0 = screen1(c0.x, c0.y, c0.z, c0.w, sxf, syf, szf, dxf, dyf, dzf);
+    e1 = screen1(c1.x, c1.y, c1.z, c1.w, sxf, syf, szf, dxf, dyf, dzf);
+    e2 = screen1(c2.x, c2.y, c2.z, c2.w, sxf, syf, szf, dxf, dyf, dzf);
+    e3 = screen1(c3.x, c3.y, c3.z, c3.w, sxf, syf, szf, dxf, dyf, dzf);
+#endif
+}
+
+// Two-level screen for sphere-only scenes: the host cuts the spheres into spatially compact groups of 8 (leaves of
+// a k-d tree); each group has a bounding ball (centre g, radius R >= |c_k - g| + r_k for its members, plus a
+// margin of 0.1).  A ray whose screening value for the bounding ball is below its threshold misses the ball by
+// more than the margin, hence (distance to a line is 1-Lipschitz) misses every member's sphere by more than the
+// margin, hence every member's double-precision discriminant in the reference is negative: the whole group is
+// skipped.  Members of the other groups go through the per-sphere screen and the exact test as before.  The
+// margin covers what separates "misses the ball" from "negative computed discriminant": the direction's
+// deviation from unit length (|d.d - 1| < 1e-15 after vecUnit) times b*b, and the reference's own rounding;
+// both are below 2e-4 for coordinates under 1e5, which is what packGroupedTable and the caller require.
+// Spheres are then met out of index order, so ties are broken by index explicitly (exactSphere); without planes
+// and with finite coordinates no distance is NaN, so the winner does not depend on the order of the visits.
+template <int AVOID, bool LDSGEOM, bool EXACTLDS>
+__device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double sx, double sy, double sz, double dx,
+                                                  double dy, double dz, int avoidShape,
+                                                  const unsigned char *avoidRow, float negThreshold, Hit &h) {
+    const float4v *groups = LDSGEOM ? (const float4v *)ldsGeom : (const float4v *)P.geomF;
+    const float4v *members = groups + P.memberBase;
+    const double *geom = EXACTLDS ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
+    double minDist = -1;
+    h.idx = -1;
+    h.slot = 0;
+    h.kind = 0;
+    h.x = h.y = h.z = 0;
+    const float sxf = (float)sx, syf = (float)sy, szf = (float)sz;
+    const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
+    auto members4 = [&](const float4v *mb, int pos) {
+        float f0, f1, f2, f3;
+        screenBlock(mb[0], mb[1], mb[2], mb[3], sxf, syf, szf, dxf, dyf, dzf, f0, f1, f2, f3);
+        const float best = __builtin_fmaxf(__builtin_fmaxf(f0, f1), __builtin_fmaxf(f2, f3));
+        if (!(best < negThreshold)) {
+#pragma nounroll
+            for (int v = 0; v < 4; ++v) {
+                const float fv = v == 0 ? f0 : v == 1 ? f1 : v == 2 ? f2 : f3;
+                if (!(fv < negThreshold)) {
+                    const int shape = P.memberShape[pos + v];
+                    bool skip = shape < 0;
+                    if (AVOID == 1) skip = skip || shape == avoidShape;
+                    if (AVOID == 2) skip = skip || (avoidRow && shape >= 0 && avoidRow[shape]);
+#ifdef GRAFT_STAMPS
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
+#endif
+                    if (!skip) exactSphere(geom, shape, shape, sx, sy, sz, dx, dy, dz, minDist, h);
+                }
+            }
+        }
+    };
+    auto groups4 = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j) {
+        float e0, e1, e2, e3;
+        screenBlock(c0, c1, c2, c3, sxf, syf, szf, dxf, dyf, dzf, e0, e1, e2, e3);
+        const float best = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
+        if (!(best < negThreshold)) {  // some lane's ray comes near one of these four bounding balls
+#pragma nounroll
+            for (int u = 0; u < 4; ++u) {
+                const float eu = u == 0 ? e0 : u == 1 ? e1 : u == 2 ? e2 : e3;
+                if (!(eu < negThreshold)) {
+#ifdef GRAFT_STAMPS
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
+#endif
+                    const float4v *mb = members + (size_t)(j + u) * 8;
+                    members4(mb, (j + u) * 8);
+                    members4(mb + 4, (j + u) * 8 + 4);
+                }
+            }
+        }
+    };
+    float4v a0 = groups[0], a1 = groups[1], a2 = groups[2], a3 = groups[3];
+    for (int j = 0; j < P.groupEntries; j += 8) {
+        const float4v b0 = groups[j + 4], b1 = groups[j + 5], b2 = groups[j + 6], b3 = groups[j + 7];
+        groups4(a0, a1, a2, a3, j);
+        a0 = groups[j + 8]; a1 = groups[j + 9]; a2 = groups[j + 10]; a3 = groups[j + 11];
+        groups4(b0, b1, b2, b3, j + 4);
+    }
+}
+
+// fresnel() of the reference, mainTracing.c:273-294, bug for bug: the two indices live in `float`, sinN is
+// rounded to float, and the double result is truncated to int, so the weight is 0 unless it is exactly 1.
+// Float division and multiplication are done through double (exact product / correctly rounded quotient, then
+// one rounding to float), which equals the IEEE single-precision operation the CPU performs.
+__device__ __forceinline__ int fresnelWeight(double refrIndex, const double n[3], const double d[3]) {
+    double cosD = dot3(n[0], n[1], n[2], d[0], d[1], d[2]);
+    if (cosD < -1) cosD = -1;
+    if (cosD > 1) cosD = 1;
+    float etaD = 1, etaN = (float)refrIndex;
+    if (cosD > 0) {
+        etaD = etaN;
+        etaN = 1;
+    }
+    const float ratio = (float)((double)etaD / (double)etaN);
+    const double under = (1 - cosD * cosD) < 0 ? 0 : (1 - cosD * cosD);
+    const float sinN = (float)((double)ratio * sqrt(under));
+    if (sinN >= 1) return 1;
+    const float sq = (float)((double)sinN * (double)sinN);
+    const float rest = (float)(1.0 - (double)sq);
+    const double cosN = sqrt((double)(rest < 0 ? 0.0f : rest));
+    cosD = fabs(cosD);
+    const double Rs = (((double)etaN * cosD) - ((double)etaD * cosN)) / (((double)etaN * cosD) + ((double)etaD * cosN));
+    const double Rp = (((double)etaD * cosD) - ((double)etaN * cosN)) / (((double)etaD * cosD) + ((double)etaN * cosN));
+    return (int)((Rs * Rs + Rp * Rp) / 2);
+}
+
+// The ray refraction() shoots, mainTracing.c:232-265, bug for bug: the POSITION (not the direction) is scaled by
+// eta and serves both in the refracted direction and as the ray's origin.  Returns the child's shouldReflect.
+__device__ __forceinline__ int refractionRay(double refrIndex, const double loc[3], const double d[3],
+                                             const double nrm[3], double o[3], double dir[3]) {
+    int childReflects = 1;
+    double s[3] = {loc[0], loc[1], loc[2]};
+    double n[3] = {nrm[0], nrm[1], nrm[2]};
+    double cosD = dot3(d[0], d[1], d[2], nrm[0], nrm[1], nrm[2]);
+    if (cosD < -1) cosD = -1;
+    if (cosD > 1) cosD = 1;
+    double etaD = 1, etaN = refrIndex;
+    if (cosD < 0) {
+        cosD = -cosD;
+    } else {
+        etaD = etaN;
+        etaN = 1;
+        n[0] = -1 * n[0]; n[1] = -1 * n[1]; n[2] = -1 * n[2];
+        childReflects = 0;
+    }
+    const double eta = etaD / etaN;
+    const double k = 1 - eta * eta * (1 - cosD * cosD);
+    if (k < 0) {
+        dir[0] = d[0]; dir[1] = d[1]; dir[2] = d[2];
+    } else {
+        s[0] = eta * s[0]; s[1] = eta * s[1]; s[2] = eta * s[2];
+        const double f = eta * cosD - sqrt(k);
+        n[0] = f * n[0]; n[1] = f * n[1]; n[2] = f * n[2];
+        dir[0] = s[0] + n[0]; dir[1] = s[1] + n[1]; dir[2] = s[2] + n[2];
+    }
+    unit3(dir[0], dir[1], dir[2], dir[0], dir[1], dir[2]);
+    o[0] = s[0] + .000001 * dir[0];
+    o[1] = s[1] + .000001 * dir[1];
+    o[2] = s[2] + .000001 * dir[2];
+    return childReflects;
+}
+
+// ray through world offsets (xo, yo) of the screen plane: mainTracing.c:405-417 / :425-437
+__device__ __forceinline__ void primaryRay(const TraceParams &P, double xo, double yo, double o[3], double d[3]) {
+    double col[3];
+    newPoint(P.screenCenter, P.lrVec, P.lrDen, xo, col);
+    newPoint(col, P.udVec, P.udDen, yo, o);
+    d[0] = d[1] = d[2] = 0;
+    if (P.projectionType == GRAFT_ORTHOGRAPHIC) unit3(-P.viewDir[0], -P.viewDir[1], -P.viewDir[2], d[0], d[1], d[2]);
+    else unit3(o[0] - P.camPos[0], o[1] - P.camPos[1], o[2] - P.camPos[2], d[0], d[1], d[2]);
+}
+
+__device__ __forceinline__ unsigned quant8(double v) {
+    double c = v < 0 ? 0 : (v > 1 ? 1 : v);
+    if (!(v == v)) c = 0;
+    return (unsigned)(c * 255 + 0.5);
+}
+
+
+}  // namespace graft

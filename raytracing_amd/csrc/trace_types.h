@@ -1,0 +1,88 @@
+// trace_types.h -- constants and plain structs shared by the device code and the host-side packers of
+// libgrafthip.so (included by grafthip.hip only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "grafthip.h"
+
+namespace graft {
+
+
+constexpr int kTile = 8;            // 8x8 pixels = one wave64
+constexpr int kMaxDepth = 12;       // levels of the reflection chain kept per lane
+constexpr int kSmallBlock = 256;    // scenes whose geometry fits a quarter of the LDS
+#ifndef GRAFT_LARGE_BLOCK
+#define GRAFT_LARGE_BLOCK 1024
+#endif
+constexpr int kLargeBlock = GRAFT_LARGE_BLOCK;   // one workgroup per CU sharing up to the whole LDS
+constexpr size_t kLdsSmall = 36 * 1024;
+constexpr size_t kLdsMax = 152 * 1024;
+
+struct DevRun {  // shapes [firstShape, firstShape+count) are all of `kind`; their geometry starts at slot
+    int kind, firstShape, count, slot;
+    int fslot;    // sphere runs: first entry of the run's block in the single-precision screen table
+    int fcount;   // entries of that block: count rounded up to a multiple of 8 with never-passing dummies
+    int pad[2];
+};
+
+struct DevMaterial {  // 64 bytes per shape
+    double color[3];
+    double reflectivity, ambientLight, transparency, refrIndex;
+    int slot, kind;
+};
+
+struct DevLight {  // 64 bytes per light
+    double color[3];
+    double loc[3];
+    int avoidFirst;  // the one avoided shape (avoid mode 1) or -1
+    int avoidNum;
+    int pad[2];
+};
+
+struct TraceParams {
+    // camera (mainTracing.c:54-62 after camInitialize)
+    double screenCenter[3], camPos[3], viewDir[3], lrVec[3], udVec[3];
+    double lrDen, udDen;  // dir.dir of lrVec / udVec as getNewPoint forms it (mainTracing.c:107)
+    double background[3];
+    double subStepX, subStepY;
+    int projectionType, aliasing, numPasses, maxDepth;
+    int numShapes, numLights, numRuns, numSpheres;
+    int nCols, nRows;          // whole frame
+    int row0, bandRows;        // rows traced by this launch
+    int tilesX, numTiles;
+    int tilesPerTicket, pad1;  // consecutive tiles a wave takes per draw from the cursor
+    int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
+    int format;
+    int filterFloats;          // floats of the single-precision screen table staged in LDS, 0 = no screen
+    int groupEntries;          // grouped screen: entries of the group table (multiple of 8), 0 = not grouped
+    int memberBase;            // grouped screen: first entry (float4 index) of the member table inside the screen table
+    int exactLdsOffset;        // bytes from the start of LDS to the staged exact doubles (EXACTLDS kernels)
+    const int *memberShape;    // grouped screen: shape index of every member-table entry, -1 = padding
+    const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
+    const double *geom;
+    const DevRun *runs;
+    const DevMaterial *materials;
+    const DevLight *lights;
+    const unsigned char *avoidMask;  // [numLights][numShapes], avoid mode 2 only
+    const double *colOff, *rowOff;
+    void *frame;
+    int *hitIndex;
+    unsigned long long *counters;  // {rays, tests} or null
+    int *tileCursor;
+};
+
+extern __shared__ __attribute__((aligned(32))) double ldsGeom[];
+
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+enum { M_RADIANCE = 0, M_SHADOW = 1, M_INDEX = 2, M_DONE = 3 };
+enum { F_MIRROR_PENDING = 1, F_HAS_REFRACTION = 2, F_REFRACTION_REFLECTS = 4 };
+
+struct Hit {
+    int idx, slot, kind;
+    double x, y, z;
+};
+
+
+}  // namespace graft
