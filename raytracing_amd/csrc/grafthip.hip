@@ -19,6 +19,7 @@
 #include <new>
 #include <vector>
 #include <algorithm>
+#include <array>
 #include <utility>
 
 #include "grafthip.h"
@@ -31,7 +32,8 @@ using namespace graft;
 
 namespace {
 
-// SCREEN: 0 = exact double loop, 1 = single-precision screen per sphere, 2 = two-level screen.
+// SCREEN: 0 = exact double loop, 1 = single-precision screen per sphere, 2 = two-level ball screen,
+// 3 = two-level screens per ray family (cones for primary and shadow rays, balls for the rest; LDS only).
 // LDSGEOM: the table the hot loop reads (screen table, or the doubles when SCREEN == 0) is staged in LDS.
 // EXACTLDS (SCREEN > 0 only): the exact doubles are staged in LDS as well, behind the screen table; otherwise the
 // rare exact tests read them from global memory.
@@ -149,9 +151,15 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 if (SCREEN) {
                     const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
                     const bool tame = s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001;
-                    if (tame && (SCREEN == 1 || s1 < 1e5)) {
+                    if (tame && (SCREEN == 1 || s1 < (SCREEN == 3 ? P.familyScale : 1e5))) {
                         const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
-                        if (SCREEN == 2) closestHitGrouped<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
+                        if (SCREEN == 3) {
+                            // which fixed point the ray's line passes through decides the table it is screened with
+                            int family = P.ballFamily;
+                            if (mode == M_SHADOW) family = P.lightFamilyBase + li;
+                            else if ((mode == M_INDEX || depth == 0) && P.cameraFamily >= 0) family = P.cameraFamily;
+                            closestHitFamilies<AVOID, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, family, negThreshold, h);
+                        } else if (SCREEN == 2) closestHitGrouped<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
                         else closestHitScreened<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
                     } else {  // exact loop over the doubles in global memory
                         closestHit<AVOID, false>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
@@ -431,7 +439,8 @@ TraceFn pickKernelA(bool lds, int screen, bool exactLds) {
     if (!lds) return screen == 2 ? traceKernel<A, false, 2, false, false> : screen == 1 ? traceKernel<A, false, 1, false, false> : traceKernel<A, false, 0, false, false>;
     if (screen == 0) return traceKernel<A, true, 0, false, false>;
     if (screen == 1) return exactLds ? traceKernel<A, true, 1, true, false> : traceKernel<A, true, 1, false, false>;
-    return exactLds ? traceKernel<A, true, 2, true, false> : traceKernel<A, true, 2, false, false>;
+    if (screen == 2) return exactLds ? traceKernel<A, true, 2, true, false> : traceKernel<A, true, 2, false, false>;
+    return exactLds ? traceKernel<A, true, 3, true, false> : traceKernel<A, true, 3, false, false>;
 }
 
 // Scenes with a transparent shape run the tree-walk kernels, built only for the general avoid mode, screen
@@ -450,7 +459,7 @@ TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool tran
 struct GraftJob {
     TraceParams P;
     int avoidMode;
-    int screen;   // 0 = exact only, 1 = single-precision screen per sphere, 2 = two-level (grouped) screen
+    int screen;   // 0 = exact only, 1 = screen per sphere, 2 = two-level ball screen, 3 = per-family two-level screens
     bool lds;
     bool exactLds;  // exact doubles staged in LDS behind the screen table
     bool transp;    // some shape is transparent: tree-walk kernel
@@ -484,7 +493,7 @@ GRAFT_API int graftInit(int device) {
     gNumCU = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&gStream, hipStreamNonBlocking));
     for (int a = 0; a < 3; ++a)
-        for (int f = 0; f < 3; ++f)
+        for (int f = 0; f < 4; ++f)
             for (int x = 0; x < 2; ++x)
                 for (int t = 0; t < 2; ++t)
                     HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f, x != 0, t != 0),
@@ -658,16 +667,57 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     P.geomDoubles = (int)(sph.size() + pln.size());
 
     // GRAFT_SCREEN in the environment caps the screen level (diagnostics and A/B timing): 0 = exact double loop
-    // only, 1 = single-precision screen per sphere, 2 (default) = two-level screen where the scene qualifies
+    // only, 1 = single-precision screen per sphere, 2 = two-level ball screen, 3 (default) = per-family two-level
+    // screens; each level is used only where the scene qualifies for it
     const char *env = getenv("GRAFT_SCREEN");
-    const int screenCap = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : 2;
+    const int screenCap = env && env[0] >= '0' && env[0] <= '3' ? env[0] - '0' : 3;
     int screen = (screenCap >= 1 && !sph.empty()) ? 1 : 0;
     if (transparent) avoidMode = 2;  // the tree-walk kernels exist for the general avoid mode only
     std::vector<float> tableF;
     std::vector<int> memberShape;
-    if (screen && screenCap >= 2 && pln.empty() && !transparent &&
-        packGroupedTable(sph, tableF, memberShape, P.groupEntries, P.memberBase)) screen = 2;
-    if (screen != 2) { P.groupEntries = 0; P.memberBase = 0; memberShape.clear(); }
+    TwoLevelTable balls;
+    if (screen && screenCap >= 2 && pln.empty() && !transparent && packBallTable(sph, balls)) {
+        screen = 2;
+        tableF = balls.entries;
+        memberShape = balls.memberShape;
+        P.groupEntries = balls.groupEntries;
+        P.memberBase = balls.memberBase;
+    }
+    // per-family tables: cones seen from the camera (perspective only) and from every light, then the ball table
+    if (screen == 2 && screenCap >= 3 && nL <= 7) {
+        std::vector<std::array<double, 3>> apexes;
+        if (view->projectionType == GRAFT_PERSPECTIVE) apexes.push_back({view->camPos[0], view->camPos[1], view->camPos[2]});
+        const int lightBase = (int)apexes.size();
+        for (int i = 0; i < nL; ++i) apexes.push_back({lights[i].loc[0], lights[i].loc[1], lights[i].loc[2]});
+        // scale: the largest |.|_1 of anything a screened ray can start from or aim at
+        double scale = 0, offs = fabs(view->subStepX) * (view->numPasses + 1) + fabs(view->subStepY) * (view->numPasses + 1);
+        double colMax = 0, rowMax = 0;
+        for (int i = 0; i < view->nCols; ++i) colMax = fmax(colMax, fabs(view->colOffsets[i]));
+        for (int i = 0; i < view->nRows; ++i) rowMax = fmax(rowMax, fabs(view->rowOffsets[i]));
+        scale = fabs(view->screenCenter[0]) + fabs(view->screenCenter[1]) + fabs(view->screenCenter[2]) + 2 * (colMax + rowMax + offs);
+        for (size_t k = 0; k < sph.size() / 4; ++k)
+            scale = fmax(scale, fabs(sph[4 * k]) + fabs(sph[4 * k + 1]) + fabs(sph[4 * k + 2]) + sqrt(sph[4 * k + 3]));
+        for (const auto &a : apexes) scale = fmax(scale, fabs(a[0]) + fabs(a[1]) + fabs(a[2]));
+        if (!apexes.empty() && scale < kGroupScale) {  // (NaN fails the comparison)
+            std::vector<TwoLevelTable> fam(apexes.size() + 1);
+            for (size_t f = 0; f < apexes.size(); ++f) packConeTable(sph, apexes[f].data(), scale, fam[f]);
+            fam.back() = balls;
+            std::vector<float> inter;
+            std::vector<int> interShape;
+            interleaveFamilies(fam, inter, interShape);
+            if (sizeof(float) * inter.size() <= kLdsMax) {
+                screen = 3;
+                tableF.swap(inter);
+                memberShape.swap(interShape);
+                P.families = (int)fam.size();
+                P.ballFamily = (int)fam.size() - 1;
+                P.cameraFamily = lightBase ? 0 : -1;
+                P.lightFamilyBase = lightBase;
+                P.familyScale = scale;
+            }
+        }
+    }
+    if (screen < 2) { P.groupEntries = 0; P.memberBase = 0; memberShape.clear(); }
     if (screen == 1) packScreenTable(sph, runs, tableF);
     P.filterFloats = (int)tableF.size();
 

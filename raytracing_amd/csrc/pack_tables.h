@@ -80,101 +80,217 @@ constexpr int kGroup = 8;          // spheres per group of the two-level screen
 constexpr double kGroupMargin = 0.1;
 constexpr double kGroupScale = 1e5;  // coordinates must stay below this for the margin to cover the rounding terms
 
-// Two-level screen table for a scene of spheres only (see closestHitGrouped).  Layout, in entries of 4 floats:
-// [group table: bounding balls, 4 per block, padded to a multiple of 8][8 entries of padding: the loop fetches two
-// blocks ahead][member table: 8 entries (2 blocks) per group].  Returns false when the scene does not qualify.
-bool packGroupedTable(const std::vector<double> &sph, std::vector<float> &out, std::vector<int> &memberShape,
-                      int &groupEntries, int &memberBase) {
+// Order of n points (3 doubles each) such that every run of kGroup consecutive points is a leaf of a k-d tree:
+// split the longest axis of the bounding box at the median (left part a multiple of kGroup) until at most kGroup
+// points remain; ties by index, so the result is deterministic.
+inline std::vector<int> kdLeafOrder(const std::vector<double> &pts, int n) {
+    std::vector<int> idx(n);
+    for (int k = 0; k < n; ++k) idx[k] = k;
+    std::vector<std::pair<int, int>> todo{{0, n}};
+    while (!todo.empty()) {
+        const std::pair<int, int> seg = todo.back();
+        todo.pop_back();
+        const int count = seg.second - seg.first;
+        if (count <= kGroup) continue;
+        double blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = seg.first; i < seg.second; ++i)
+            for (int a = 0; a < 3; ++a) {
+                blo[a] = fmin(blo[a], pts[3 * (size_t)idx[i] + a]);
+                bhi[a] = fmax(bhi[a], pts[3 * (size_t)idx[i] + a]);
+            }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (bhi[a] - blo[a] > bhi[axis] - blo[axis]) axis = a;
+        const int half = (count / 2 + kGroup - 1) / kGroup * kGroup;
+        std::sort(idx.begin() + seg.first, idx.begin() + seg.second, [&](int x, int y) {
+            const double cx = pts[3 * (size_t)x + axis], cy = pts[3 * (size_t)y + axis];
+            return cx < cy || (cx == cy && x < y);
+        });
+        todo.push_back({seg.first, seg.first + half});
+        todo.push_back({seg.first + half, seg.second});
+    }
+    return idx;
+}
+
+// One two-level table: [group entries, padded to a multiple of 8][8 entries of padding: the loop fetches two blocks
+// ahead][8 member entries (2 blocks) per group][8 entries of padding], 4 floats per entry, packed in blocks of 4
+// (putEntry); memberShape[g * 8 + m] is the shape index of a member entry, -1 for padding.
+struct TwoLevelTable {
+    std::vector<float> entries;
+    std::vector<int> memberShape;
+    int groupEntries = 0, memberBase = 0;
+    void shape(int n, float neverPass) {
+        const int nGroups = (n + kGroup - 1) / kGroup;
+        groupEntries = (nGroups + 7) / 8 * 8;
+        memberBase = groupEntries + 8;
+        const size_t total = (size_t)memberBase + (size_t)nGroups * kGroup + 8;
+        entries.assign(4 * total, 0.0f);
+        memberShape.assign((size_t)nGroups * kGroup, -1);
+        for (size_t i = 0; i < total; ++i) putEntry(entries.data() + 16 * (i / 4), (int)(i % 4), 0.0f, 0.0f, 0.0f, neverPass);
+    }
+    void group(int g, float x, float y, float z, float w) { putEntry(entries.data() + 16 * (g / 4), g % 4, x, y, z, w); }
+    void member(int g, int m, int shapeIndex, float x, float y, float z, float w) {
+        const size_t e = (size_t)memberBase + (size_t)g * kGroup + m;
+        putEntry(entries.data() + 16 * (e / 4), (int)(e % 4), x, y, z, w);
+        memberShape[(size_t)g * kGroup + m] = shapeIndex;
+    }
+};
+
+// Two-level BALL table for a scene of spheres only (see closestHitGrouped): groups are k-d leaves of the centres,
+// each with a bounding ball.  Returns false when the scene does not qualify.
+inline bool packBallTable(const std::vector<double> &sph, TwoLevelTable &T) {
     const int n = (int)(sph.size() / 4);
     if (n < 64) return false;
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    std::vector<double> pts(3 * (size_t)n);
     for (int k = 0; k < n; ++k) {
         const double *c = &sph[4 * (size_t)k];
-        const double r = sqrt(c[3]);
-        if (!(fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + r < kGroupScale)) return false;  // also rejects NaN
-        for (int a = 0; a < 3; ++a) { lo[a] = fmin(lo[a], c[a]); hi[a] = fmax(hi[a], c[a]); }
+        if (!(fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + sqrt(c[3]) < kGroupScale)) return false;  // also rejects NaN
+        for (int a = 0; a < 3; ++a) pts[3 * (size_t)k + a] = c[a];
     }
-    // groups = leaves of a k-d tree: split the longest axis of the centres' bounding box at the median (left part a
-    // multiple of the group size) until at most kGroup spheres remain; ties by index, so the result is deterministic
-    std::vector<std::pair<unsigned, int>> order(n);
-    {
-        std::vector<int> idx(n);
-        for (int k = 0; k < n; ++k) idx[k] = k;
-        std::vector<std::pair<int, int>> todo{{0, n}};
-        while (!todo.empty()) {
-            const std::pair<int, int> seg = todo.back();
-            todo.pop_back();
-            const int count = seg.second - seg.first;
-            if (count <= kGroup) continue;
-            double blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (int i = seg.first; i < seg.second; ++i)
-                for (int a = 0; a < 3; ++a) {
-                    blo[a] = fmin(blo[a], sph[4 * (size_t)idx[i] + a]);
-                    bhi[a] = fmax(bhi[a], sph[4 * (size_t)idx[i] + a]);
-                }
-            int axis = 0;
-            for (int a = 1; a < 3; ++a)
-                if (bhi[a] - blo[a] > bhi[axis] - blo[axis]) axis = a;
-            const int half = (count / 2 + kGroup - 1) / kGroup * kGroup;
-            std::sort(idx.begin() + seg.first, idx.begin() + seg.second, [&](int x, int y) {
-                const double cx = sph[4 * (size_t)x + axis], cy = sph[4 * (size_t)y + axis];
-                return cx < cy || (cx == cy && x < y);
-            });
-            todo.push_back({seg.first, seg.first + half});
-            todo.push_back({seg.first + half, seg.second});
-        }
-        for (int k = 0; k < n; ++k) order[k] = {0u, idx[k]};
-    }
+    const std::vector<int> order = kdLeafOrder(pts, n);
+    T.shape(n, -INFINITY);  // rho = -inf never passes
     const int nGroups = (n + kGroup - 1) / kGroup;
-    groupEntries = (nGroups + 7) / 8 * 8;
-    memberBase = groupEntries + 8;
-    out.assign(4 * ((size_t)memberBase + (size_t)nGroups * kGroup + 8), 0.0f);
-    memberShape.assign((size_t)nGroups * kGroup, -1);
-    for (int i = 0; i < memberBase; ++i) putEntry(out.data() + 16 * (i / 4), i % 4, 0.0f, 0.0f, 0.0f, -INFINITY);
     for (int gI = 0; gI < nGroups; ++gI) {
         const int first = gI * kGroup, last = std::min(n, first + kGroup);
         // centre of the bounding ball: start at the centroid and walk towards the farthest sphere with shrinking
         // steps (Badoiu-Clarkson); any centre is valid, the radius below is what makes the ball enclose the members
         double g[3] = {0, 0, 0};
         for (int m = first; m < last; ++m)
-            for (int a = 0; a < 3; ++a) g[a] += sph[4 * (size_t)order[m].second + a] / (last - first);
+            for (int a = 0; a < 3; ++a) g[a] += sph[4 * (size_t)order[m] + a] / (last - first);
         for (int it = 0; it < 64; ++it) {
             int far = first;
             double farDist = -1;
             for (int m = first; m < last; ++m) {
-                const double *c = &sph[4 * (size_t)order[m].second];
+                const double *c = &sph[4 * (size_t)order[m]];
                 const double dx = c[0] - g[0], dy = c[1] - g[1], dz = c[2] - g[2];
                 const double dd = sqrt(dx * dx + dy * dy + dz * dz) + sqrt(c[3]);
                 if (dd > farDist) { farDist = dd; far = m; }
             }
-            const double *c = &sph[4 * (size_t)order[far].second];
+            const double *c = &sph[4 * (size_t)order[far]];
             for (int a = 0; a < 3; ++a) g[a] += (c[a] - g[a]) / (it + 2);
         }
         double R = 0;
         for (int m = first; m < last; ++m) {
-            const double *c = &sph[4 * (size_t)order[m].second];
+            const double *c = &sph[4 * (size_t)order[m]];
             const double dx = c[0] - g[0], dy = c[1] - g[1], dz = c[2] - g[2];
             R = fmax(R, sqrt(dx * dx + dy * dy + dz * dz) + sqrt(c[3]));
         }
         R = R * (1.0 + 1e-9) + kGroupMargin;
         float rho;
         if (!screenRho(g, R * R * (1.0 + 1e-12), rho)) return false;
-        putEntry(out.data() + 16 * (gI / 4), gI % 4, (float)g[0], (float)g[1], (float)g[2], rho);
-        float *mblk = out.data() + 4 * ((size_t)memberBase + (size_t)gI * kGroup);
-        for (int m = 0; m < kGroup; ++m) {
-            float *blk = mblk + 16 * (m / 4);
-            if (first + m >= last) { putEntry(blk, m % 4, 0.0f, 0.0f, 0.0f, -INFINITY); continue; }
-            const int k = order[first + m].second;
+        T.group(gI, (float)g[0], (float)g[1], (float)g[2], rho);
+        for (int m = first; m < last; ++m) {
+            const int k = order[m];
             const double *c = &sph[4 * (size_t)k];
             if (!screenRho(c, c[3], rho)) return false;
-            putEntry(blk, m % 4, (float)c[0], (float)c[1], (float)c[2], rho);
-            memberShape[(size_t)gI * kGroup + m] = k;
+            T.member(gI, m - first, k, (float)c[0], (float)c[1], (float)c[2], rho);
         }
     }
-    const size_t tail = (size_t)memberBase + (size_t)nGroups * kGroup;
-    for (int i = 0; i < 8; ++i) putEntry(out.data() + 4 * tail + 16 * (i / 4), i % 4, 0.0f, 0.0f, 0.0f, -INFINITY);
     return true;
 }
 
+// Largest float <= x
+inline float floatBelow(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = nextafterf(f, -INFINITY);
+    return f;
+}
+
+// Two-level CONE table for the rays that pass through one fixed point `apex` (the camera position for primary
+// rays, a light's position for its shadow rays; see closestHitFamilies).  Seen from the apex, sphere k is a cone
+// of half-angle alpha_k = asin(r_k / |c_k - apex|) around u_k = (c_k - apex)/|c_k - apex|; a line through the apex
+// with unit direction d meets the sphere iff |u_k . d| >= cos(alpha_k).  Groups are k-d leaves of the directions
+// u_k, each with an enclosing cone (axis a, half-angle theta >= angle(a, u_k) + alpha_k).  An entry holds
+// (a or u, kappa2) and passes iff (a . d)^2 - kappa2 >= 0, evaluated in single precision; kappa2 is
+// cos^2(angle + margin) - 16 u, rounded down, where
+//   - 16 u (u = 2^-24) covers rounding a and d to float and the float evaluation (|error of the dot| <= 5.1 u),
+//   - margin = 1.01 sqrt(eBound) / distance makes the exact discriminant of every culled sphere smaller than
+//     -eBound, and eBound = 1e-13 (4 S)^2 exceeds, for coordinates below S, the sum of: the reference's own rounding
+//     of the discriminant (< 3.3e-15 (|s|_1 + |c|_1)^2), the direction's deviation from unit length times b^2, and
+//     the distance (a few ulps of the coordinates) by which a computed ray misses the apex.
+// kappa2 = -1 always passes (apex inside or near the sphere, or a cone wider than 80 degrees); +inf never passes.
+inline void packConeTable(const std::vector<double> &sph, const double apex[3], double scale, TwoLevelTable &T) {
+    const int n = (int)(sph.size() / 4);
+    const double u = 5.9604644775390625e-08;
+    const double eBound = 1e-13 * (4 * scale) * (4 * scale);
+    const double kWide = 1.4;  // radians; wider cones always pass
+    std::vector<double> dir(3 * (size_t)n), alpha(n), dist(n);
+    for (int k = 0; k < n; ++k) {
+        const double *c = &sph[4 * (size_t)k];
+        const double w[3] = {c[0] - apex[0], c[1] - apex[1], c[2] - apex[2]};
+        const double len = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const double r = sqrt(c[3]);
+        dist[k] = len;
+        if (len > r * (1 + 1e-9) + 1e-9 * scale) {
+            alpha[k] = asin(r / len);
+            for (int a = 0; a < 3; ++a) dir[3 * (size_t)k + a] = w[a] / len;
+        } else {  // the apex is inside (or on) the sphere: every line through it meets the sphere
+            alpha[k] = M_PI;
+            dir[3 * (size_t)k] = 1; dir[3 * (size_t)k + 1] = 0; dir[3 * (size_t)k + 2] = 0;
+            if (len > 0) for (int a = 0; a < 3; ++a) dir[3 * (size_t)k + a] = w[a] / len;
+        }
+    }
+    auto angle = [](const double *p, const double *q) {  // accurate for small angles
+        const double cx = p[1] * q[2] - p[2] * q[1], cy = p[2] * q[0] - p[0] * q[2], cz = p[0] * q[1] - p[1] * q[0];
+        return atan2(sqrt(cx * cx + cy * cy + cz * cz), p[0] * q[0] + p[1] * q[1] + p[2] * q[2]);
+    };
+    auto kappa2 = [&](double ang, double nearest) -> float {
+        const double margin = 1.01 * sqrt(eBound) / nearest + 1e-7;
+        if (!(ang + margin < kWide)) return -1.0f;
+        const double c = cos(ang + margin);
+        return floatBelow(c * c - 16 * u);
+    };
+    const std::vector<int> order = kdLeafOrder(dir, n);
+    T.shape(n, INFINITY);  // kappa2 = +inf never passes
+    const int nGroups = (n + kGroup - 1) / kGroup;
+    for (int gI = 0; gI < nGroups; ++gI) {
+        const int first = gI * kGroup, last = std::min(n, first + kGroup);
+        double a[3] = {0, 0, 0};
+        for (int m = first; m < last; ++m)
+            for (int c = 0; c < 3; ++c) a[c] += dir[3 * (size_t)order[m] + c];
+        auto normalise = [&]() {
+            const double len = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+            if (len > 1e-12) { a[0] /= len; a[1] /= len; a[2] /= len; }
+            else { a[0] = 1; a[1] = 0; a[2] = 0; }
+        };
+        normalise();
+        for (int it = 0; it < 64; ++it) {  // walk the axis towards the member that sticks out most
+            int far = first;
+            double farAng = -1;
+            for (int m = first; m < last; ++m) {
+                const double t = angle(a, &dir[3 * (size_t)order[m]]) + alpha[order[m]];
+                if (t > farAng) { farAng = t; far = m; }
+            }
+            for (int c = 0; c < 3; ++c) a[c] += (dir[3 * (size_t)order[far] + c] - a[c]) / (it + 2);
+            normalise();
+        }
+        double theta = 0, nearest = INFINITY;
+        for (int m = first; m < last; ++m) {
+            theta = fmax(theta, angle(a, &dir[3 * (size_t)order[m]]) + alpha[order[m]]);
+            nearest = fmin(nearest, dist[order[m]]);
+        }
+        T.group(gI, (float)a[0], (float)a[1], (float)a[2], kappa2(theta, nearest));
+        for (int m = first; m < last; ++m) {
+            const int k = order[m];
+            T.member(gI, m - first, k, (float)dir[3 * (size_t)k], (float)dir[3 * (size_t)k + 1],
+                     (float)dir[3 * (size_t)k + 2], kappa2(alpha[k], dist[k]));
+        }
+    }
+}
+
+// Interleave the tables of several ray families entry by entry: entry e of family f lands at float4 index
+// e * families + f, and the shape index of member entry i at i * families + f.  Lanes of one wave that trace rays of
+// different families then read neighbouring 16-byte slots, which lie in different LDS banks.
+inline void interleaveFamilies(const std::vector<TwoLevelTable> &fam, std::vector<float> &entries,
+                               std::vector<int> &memberShape) {
+    const size_t F = fam.size(), total = fam[0].entries.size() / 4, members = fam[0].memberShape.size();
+    entries.assign(4 * total * F, 0.0f);
+    memberShape.assign(members * F, -1);
+    for (size_t f = 0; f < F; ++f) {
+        for (size_t e = 0; e < total; ++e)
+            for (int c = 0; c < 4; ++c) entries[4 * (e * F + f) + c] = fam[f].entries[4 * e + c];
+        for (size_t i = 0; i < members; ++i) memberShape[i * F + f] = fam[f].memberShape[i];
+    }
+}
 
 }  // namespace graft

@@ -58,6 +58,9 @@ struct TraceParams {
     int groupEntries;          // grouped screen: entries of the group table (multiple of 8), 0 = not grouped
     int memberBase;            // grouped screen: first entry (float4 index) of the member table inside the screen table
     int exactLdsOffset;        // bytes from the start of LDS to the staged exact doubles (EXACTLDS kernels)
+    // per-family screen (SCREEN == 3): `families` interleaved two-level tables; cone families first, ball table last
+    int families, ballFamily, cameraFamily, lightFamilyBase;  // cameraFamily < 0: primary rays use the ball table
+    double familyScale;        // rays whose |origin|_1 exceeds this use the exact loop
     const int *memberShape;    // grouped screen: shape index of every member-table entry, -1 = padding
     const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
     const double *geom;
