@@ -2,6 +2,8 @@
 // screens, Fresnel/refraction, ray generation (included by grafthip.hip only; compile with -ffp-contract=off).
 #pragma once
 
+#include <type_traits>
+
 #include "trace_types.h"
 
 namespace graft {
@@ -366,19 +368,20 @@ __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double s
     }
 }
 
-// pass values of the four entries of one CONE block for a ray direction: (a . d)^2 - kappa2 (see packConeTable)
+// pass values of the four entries of one CONE block for a ray direction: (a . d)^2 - kappa2; the table holds
+// -kappa2 so that the subtraction is the addend of a fused multiply-add (see packConeTable)
 __device__ __forceinline__ void coneBlock(const float4v c0, const float4v c1, const float4v c2, const float4v c3,
                                           float dxf, float dyf, float dzf, float &p0, float &p1, float &p2, float &p3) {
     const float2v D0 = {dxf, dxf}, D1 = {dyf, dyf}, D2 = {dzf, dzf};
-    // block layout: {ax0 ax1 ay0 ay1} {az0 az1 k0 k1} {ax2 ax3 ay2 ay3} {az2 az3 k2 k3}
+    // block layout: {ax0 ax1 ay0 ay1} {az0 az1 -k0 -k1} {ax2 ax3 ay2 ay3} {az2 az3 -k2 -k3}
     float2v xa = c0.xy * D0;
     xa = __builtin_elementwise_fma(c0.zw, D1, xa);
     xa = __builtin_elementwise_fma(c1.xy, D2, xa);
-    const float2v pa = __builtin_elementwise_fma(xa, xa, -c1.zw);
+    const float2v pa = __builtin_elementwise_fma(xa, xa, c1.zw);
     float2v xb = c2.xy * D0;
     xb = __builtin_elementwise_fma(c2.zw, D1, xb);
     xb = __builtin_elementwise_fma(c3.xy, D2, xb);
-    const float2v pb = __builtin_elementwise_fma(xb, xb, -c3.zw);
+    const float2v pb = __builtin_elementwise_fma(xb, xb, c3.zw);
     p0 = pa.x; p1 = pa.y; p2 = pb.x; p3 = pb.y;
 }
 
@@ -403,55 +406,67 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
     h.x = h.y = h.z = 0;
     const float sxf = (float)sx, syf = (float)sy, szf = (float)sz;
     const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
-    const bool cone = family != P.ballFamily;
-    const float limit = cone ? 0.0f : negThreshold;  // an entry is skipped iff its value is below this
-    auto evaluate = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, float &e0, float &e1,
-                        float &e2, float &e3) {
-        if (cone) coneBlock(c0, c1, c2, c3, dxf, dyf, dzf, e0, e1, e2, e3);
-        else screenBlock(c0, c1, c2, c3, sxf, syf, szf, dxf, dyf, dzf, e0, e1, e2, e3);
-    };
-    auto members4 = [&](const float4v *mb, int pos) {
-        float f0, f1, f2, f3;
-        evaluate(mb[0], mb[F], mb[2 * F], mb[3 * F], f0, f1, f2, f3);
-        const float best = __builtin_fmaxf(__builtin_fmaxf(f0, f1), __builtin_fmaxf(f2, f3));
-        if (!(best < limit)) {
+    // One walk over the lane's table; instantiated twice (cone / ball entries) and selected per lane OUTSIDE the
+    // loops, so that a wave whose lanes all follow cone families never executes a ball instruction.
+    auto walk = [&](auto coneTag) {
+        constexpr bool CONE = decltype(coneTag)::value;
+        const float limit = CONE ? 0.0f : negThreshold;  // an entry is skipped iff its value is below this
+        auto evaluate = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, float &e0,
+                            float &e1, float &e2, float &e3) {
+            if (CONE) coneBlock(c0, c1, c2, c3, dxf, dyf, dzf, e0, e1, e2, e3);
+            else screenBlock(c0, c1, c2, c3, sxf, syf, szf, dxf, dyf, dzf, e0, e1, e2, e3);
+        };
+        auto members4 = [&](const float4v *mb, int pos) {
+            float f0, f1, f2, f3;
+            evaluate(mb[0], mb[F], mb[2 * F], mb[3 * F], f0, f1, f2, f3);
+            const float best = __builtin_fmaxf(__builtin_fmaxf(f0, f1), __builtin_fmaxf(f2, f3));
+            if (!(best < limit)) {
 #pragma nounroll
-            for (int v = 0; v < 4; ++v) {
-                const float fv = v == 0 ? f0 : v == 1 ? f1 : v == 2 ? f2 : f3;
-                if (!(fv < limit)) {
-                    const int shape = P.memberShape[(size_t)(pos + v) * F + family];
-                    bool skip = shape < 0;
-                    if (AVOID == 1) skip = skip || shape == avoidShape;
-                    if (AVOID == 2) skip = skip || (avoidRow && shape >= 0 && avoidRow[shape]);
-                    if (!skip) exactSphere(geom, shape, shape, sx, sy, sz, dx, dy, dz, minDist, h);
+                for (int v = 0; v < 4; ++v) {
+                    const float fv = v == 0 ? f0 : v == 1 ? f1 : v == 2 ? f2 : f3;
+                    if (!(fv < limit)) {
+                        const int shape = P.memberShape[(size_t)(pos + v) * F + family];
+                        bool skip = shape < 0;
+                        if (AVOID == 1) skip = skip || shape == avoidShape;
+                        if (AVOID == 2) skip = skip || (avoidRow && shape >= 0 && avoidRow[shape]);
+#ifdef GRAFT_STAMPS
+                        if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
+#endif
+                        if (!skip) exactSphere(geom, shape, shape, sx, sy, sz, dx, dy, dz, minDist, h);
+                    }
                 }
             }
-        }
-    };
-    auto groups4 = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j) {
-        float e0, e1, e2, e3;
-        evaluate(c0, c1, c2, c3, e0, e1, e2, e3);
-        const float best = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
-        if (!(best < limit)) {
+        };
+        auto groups4 = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j) {
+            float e0, e1, e2, e3;
+            evaluate(c0, c1, c2, c3, e0, e1, e2, e3);
+            const float best = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
+            if (!(best < limit)) {
 #pragma nounroll
-            for (int u = 0; u < 4; ++u) {
-                const float eu = u == 0 ? e0 : u == 1 ? e1 : u == 2 ? e2 : e3;
-                if (!(eu < limit)) {
-                    const float4v *mb = table + (size_t)(P.memberBase + (j + u) * 8) * F;
-                    members4(mb, (j + u) * 8);
-                    members4(mb + 4 * F, (j + u) * 8 + 4);
+                for (int u = 0; u < 4; ++u) {
+                    const float eu = u == 0 ? e0 : u == 1 ? e1 : u == 2 ? e2 : e3;
+                    if (!(eu < limit)) {
+#ifdef GRAFT_STAMPS
+                        if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
+#endif
+                        const float4v *mb = table + (size_t)(P.memberBase + (j + u) * 8) * F;
+                        members4(mb, (j + u) * 8);
+                        members4(mb + 4 * F, (j + u) * 8 + 4);
+                    }
                 }
             }
+        };
+        float4v a0 = table[0], a1 = table[F], a2 = table[2 * F], a3 = table[3 * F];
+        for (int j = 0; j < P.groupEntries; j += 8) {
+            const float4v *nb = table + (size_t)(j + 4) * F;
+            const float4v b0 = nb[0], b1 = nb[F], b2 = nb[2 * F], b3 = nb[3 * F];
+            groups4(a0, a1, a2, a3, j);
+            a0 = nb[4 * F]; a1 = nb[5 * F]; a2 = nb[6 * F]; a3 = nb[7 * F];
+            groups4(b0, b1, b2, b3, j + 4);
         }
     };
-    float4v a0 = table[0], a1 = table[F], a2 = table[2 * F], a3 = table[3 * F];
-    for (int j = 0; j < P.groupEntries; j += 8) {
-        const float4v *nb = table + (size_t)(j + 4) * F;
-        const float4v b0 = nb[0], b1 = nb[F], b2 = nb[2 * F], b3 = nb[3 * F];
-        groups4(a0, a1, a2, a3, j);
-        a0 = nb[4 * F]; a1 = nb[5 * F]; a2 = nb[6 * F]; a3 = nb[7 * F];
-        groups4(b0, b1, b2, b3, j + 4);
-    }
+    if (family != P.ballFamily) walk(std::true_type{});
+    else walk(std::false_type{});
 }
 
 // fresnel() of the reference, mainTracing.c:273-294, bug for bug: the two indices live in `float`, sinN is

@@ -201,7 +201,7 @@ inline float floatBelow(double x) {
 // of half-angle alpha_k = asin(r_k / |c_k - apex|) around u_k = (c_k - apex)/|c_k - apex|; a line through the apex
 // with unit direction d meets the sphere iff |u_k . d| >= cos(alpha_k).  Groups are k-d leaves of the directions
 // u_k, each with an enclosing cone (axis a, half-angle theta >= angle(a, u_k) + alpha_k).  An entry holds
-// (a or u, kappa2) and passes iff (a . d)^2 - kappa2 >= 0, evaluated in single precision; kappa2 is
+// (a or u, -kappa2) and passes iff (a . d)^2 - kappa2 >= 0, evaluated in single precision; kappa2 is
 // cos^2(angle + margin) - 16 u, rounded down, where
 //   - 16 u (u = 2^-24) covers rounding a and d to float and the float evaluation (|error of the dot| <= 5.1 u),
 //   - margin = 1.01 sqrt(eBound) / distance makes the exact discriminant of every culled sphere smaller than
@@ -241,7 +241,7 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
         return floatBelow(c * c - 16 * u);
     };
     const std::vector<int> order = kdLeafOrder(dir, n);
-    T.shape(n, INFINITY);  // kappa2 = +inf never passes
+    T.shape(n, -INFINITY);  // the table stores -kappa2: -inf never passes
     const int nGroups = (n + kGroup - 1) / kGroup;
     for (int gI = 0; gI < nGroups; ++gI) {
         const int first = gI * kGroup, last = std::min(n, first + kGroup);
@@ -269,11 +269,11 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
             theta = fmax(theta, angle(a, &dir[3 * (size_t)order[m]]) + alpha[order[m]]);
             nearest = fmin(nearest, dist[order[m]]);
         }
-        T.group(gI, (float)a[0], (float)a[1], (float)a[2], kappa2(theta, nearest));
+        T.group(gI, (float)a[0], (float)a[1], (float)a[2], -kappa2(theta, nearest));
         for (int m = first; m < last; ++m) {
             const int k = order[m];
             T.member(gI, m - first, k, (float)dir[3 * (size_t)k], (float)dir[3 * (size_t)k + 1],
-                     (float)dir[3 * (size_t)k + 2], kappa2(alpha[k], dist[k]));
+                     (float)dir[3 * (size_t)k + 2], -kappa2(alpha[k], dist[k]));
         }
     }
 }
