@@ -218,15 +218,18 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU, "frac_nofma": achieved / PEAK_FP64_NOFMA,
                          "traffic": recorded_traffic(args.workload, [W, H]), "kernel": "traceKernel", "kernel_ms": kernel_ms,
-                         "tests_per_launch": local_tests, "flop_per_test": FLOP_PER_TEST},
+                         "tests_per_launch": local_tests, "flop_per_test": FLOP_PER_TEST,
+                         "note": "achieved counts the 17 flop of the reference's brute-force test for every "
+                                 "(ray, shape) pair; the kernel proves most pairs to be misses with cheaper "
+                                 "single-precision screens, so achieved can exceed the FP64 peak"},
         }
         if world == 1 and not args.no_frame512:
             out["frame_512"] = frame_512(dev)
         if world == 1 and not args.no_cpu:
             rows = args.cpu_rows
-            if rows is None:  # aim at roughly 15 s of CPU work: ~1e8 tests/s per core
+            if rows is None:  # aim at roughly 15 s of CPU work: ~4e8 ray-shape tests/s per host core
                 per_row = max(tests / H, 1.0)
-                rows = int(max(1, min(H, 15.0 * 1.0e8 * args.cpu_cores / per_row)))
+                rows = int(max(1, min(H, 15.0 * 4.0e8 * args.cpu_cores / per_row)))
             out["cpu_baseline"] = cpu_baseline(rt, band, row0, n_rows, args.cpu_cores, rows)
         print(json.dumps(out), flush=True)
     job.close()
