@@ -45,3 +45,56 @@ def gather_bands(band, frame, n_rows, world, rank, group=None):
     if ops:
         for work in dist.batch_isend_irecv(ops):
             work.wait()
+
+
+def chunk_rows(start, count, chunks):
+    """Cut rows [start, start+count) into at most `chunks` tile-aligned pieces: list of (first row, rows)."""
+    if count <= 0:
+        return []
+    tiles = (count + TILE_ROWS - 1) // TILE_ROWS
+    chunks = max(1, min(chunks, tiles))
+    per = (tiles + chunks - 1) // chunks * TILE_ROWS
+    out = []
+    r = start
+    while r < start + count:
+        n = min(per, start + count - r)
+        out.append((r, n))
+        r += n
+    return out
+
+
+def trace_and_gather(trace, band, frame, n_rows, world, rank, chunks=8, group=None):
+    """One frame: trace this rank's band piece by piece and ship every finished piece to rank 0 while the next one
+    is being traced.  `trace(first_row, rows, tensor)` must queue the kernel that fills `tensor` (the piece's
+    [rows][cols][channels] view) on the current stream.  The transfers are queued behind the piece's kernel (RCCL
+    waits for the current stream at the time of the call) and only waited for at the end of the frame, so on a
+    strong-scaled frame the exchange hides behind the tracing of the later pieces.  Every rank cuts every band the
+    same way, so sends and receives pair up in order."""
+    start, count = band_rows(n_rows, world, rank)
+    works = []
+    if world == 1:
+        for r0, n in chunk_rows(start, count, 1):
+            trace(r0, n, band[r0 - start:r0 - start + n])
+        if frame is not None and band.data_ptr() != frame.data_ptr():
+            frame[:count].copy_(band)
+        return
+    mine = chunk_rows(start, count, chunks)
+    others = {r: chunk_rows(*band_rows(n_rows, world, r), chunks) for r in range(1, world)} if rank == 0 else {}
+    rounds = max([len(mine)] + [len(v) for v in others.values()])
+    for c in range(rounds):
+        ops = []
+        if c < len(mine):
+            r0, n = mine[c]
+            piece = band[r0 - start:r0 - start + n]
+            trace(r0, n, piece)
+            if rank != 0:
+                ops.append(dist.P2POp(dist.isend, piece, 0, group))
+        if rank == 0:
+            for r, pieces in others.items():
+                if c < len(pieces):
+                    r0, n = pieces[c]
+                    ops.append(dist.P2POp(dist.irecv, frame[r0:r0 + n], r, group))
+        if ops:
+            works.extend(dist.batch_isend_irecv(ops))
+    for w in works:
+        w.wait()

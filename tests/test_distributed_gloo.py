@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from raytracing_amd.distributed import band_rows, gather_bands
+from raytracing_amd.distributed import band_rows, chunk_rows, gather_bands, trace_and_gather
 
 
 def _free_port():
@@ -51,3 +51,46 @@ def test_gather_bands(world, n_rows):
         ret = m.dict()
         mp.spawn(_worker, args=(world, port, n_rows, 24, ret), nprocs=world, join=True)
         assert dict(ret) == {0: True, 1: True}
+
+
+def _pipeline_worker(rank, world, port, n_rows, n_cols, chunks, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        start, count = band_rows(n_rows, world, rank)
+        frame = torch.full((n_rows, n_cols, 4), -1.0) if rank == 0 else None
+        band = frame[start:start + count] if rank == 0 else torch.empty((count, n_cols, 4))
+        calls = []
+
+        def trace(first, rows, piece):  # stands for the kernel launch: fills the piece's rows
+            calls.append((first, rows))
+            r = torch.arange(first, first + rows, dtype=torch.float32).view(-1, 1, 1)
+            c = torch.arange(n_cols, dtype=torch.float32).view(1, -1, 1)
+            piece.copy_((r * 1000 + c).expand(rows, n_cols, 4))
+
+        for _ in range(2):
+            trace_and_gather(trace, band, frame, n_rows, world, rank, chunks)
+            dist.barrier()
+        assert sum(n for _, n in calls) == 2 * count and all(f % 8 == 0 for f, _ in calls)
+        if rank == 0:
+            want = (torch.arange(n_rows, dtype=torch.float32).view(-1, 1, 1) * 1000 +
+                    torch.arange(n_cols, dtype=torch.float32).view(1, -1, 1)).expand(n_rows, n_cols, 4)
+            ret[0] = bool(torch.equal(frame, want))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_rows,chunks", [(2, 128, 4), (3, 100, 8), (2, 24, 8), (2, 8, 3)])
+def test_trace_and_gather_pipeline(world, n_rows, chunks):
+    port = _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_pipeline_worker, args=(world, port, n_rows, 16, chunks, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True}
+
+
+def test_chunk_rows():
+    assert chunk_rows(0, 2048, 8) == [(i * 256, 256) for i in range(8)]
+    assert chunk_rows(16, 20, 8) == [(16, 8), (24, 8), (32, 4)]
+    assert chunk_rows(0, 0, 4) == [] and chunk_rows(8, 5, 4) == [(8, 5)]
