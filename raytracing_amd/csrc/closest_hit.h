@@ -392,7 +392,9 @@ __device__ __forceinline__ void coneBlock(const float4v c0, const float4v c1, co
 // interleaved entry by entry (entry e of family f at float4 index e * families + f), so lanes of one wave may
 // follow different families at full LDS rate.  Spheres are met out of index order; see closestHitGrouped for
 // why the winner does not depend on it.
-template <int AVOID, bool EXACTLDS>
+// MEMBERS_GLOBAL: only the group sections of all families and the ball family's member section are staged in LDS
+// (scenes whose cone member sections do not fit); cone members are then read from the table in global memory.
+template <int AVOID, bool EXACTLDS, bool MEMBERS_GLOBAL>
 __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double sx, double sy, double sz, double dx,
                                                    double dy, double dz, int avoidShape, const unsigned char *avoidRow,
                                                    int family, float negThreshold, Hit &h) {
@@ -416,9 +418,9 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
             if (CONE) coneBlock(c0, c1, c2, c3, dxf, dyf, dzf, e0, e1, e2, e3);
             else screenBlock(c0, c1, c2, c3, sxf, syf, szf, dxf, dyf, dzf, e0, e1, e2, e3);
         };
-        auto members4 = [&](const float4v *mb, int pos) {
+        auto members4 = [&](auto *mb, int stride, int pos) {
             float f0, f1, f2, f3;
-            evaluate(mb[0], mb[F], mb[2 * F], mb[3 * F], f0, f1, f2, f3);
+            evaluate(mb[0], mb[stride], mb[2 * stride], mb[3 * stride], f0, f1, f2, f3);
             const float best = __builtin_fmaxf(__builtin_fmaxf(f0, f1), __builtin_fmaxf(f2, f3));
             if (!(best < limit)) {
 #pragma nounroll
@@ -449,9 +451,19 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
 #ifdef GRAFT_STAMPS
                         if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
 #endif
-                        const float4v *mb = table + (size_t)(P.memberBase + (j + u) * 8) * F;
-                        members4(mb, (j + u) * 8);
-                        members4(mb + 4 * F, (j + u) * 8 + 4);
+                        if (!MEMBERS_GLOBAL) {
+                            const float4v *mb = table + (size_t)(P.memberBase + (j + u) * 8) * F;
+                            members4(mb, F, (j + u) * 8);
+                            members4(mb + 4 * F, F, (j + u) * 8 + 4);
+                        } else if (CONE) {
+                            const float4v *mb = (const float4v *)P.geomF + (size_t)(P.memberBase + (j + u) * 8) * F + family;
+                            members4(mb, F, (j + u) * 8);
+                            members4(mb + 4 * F, F, (j + u) * 8 + 4);
+                        } else {
+                            const float4v *mb = (const float4v *)ldsGeom + P.ballMembersLds + (j + u) * 8;
+                            members4(mb, 1, (j + u) * 8);
+                            members4(mb + 4, 1, (j + u) * 8 + 4);
+                        }
                     }
                 }
             }

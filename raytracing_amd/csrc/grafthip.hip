@@ -33,7 +33,8 @@ using namespace graft;
 namespace {
 
 // SCREEN: 0 = exact double loop, 1 = single-precision screen per sphere, 2 = two-level ball screen,
-// 3 = two-level screens per ray family (cones for primary and shadow rays, balls for the rest; LDS only).
+// 3 = two-level screens per ray family (cones for primary and shadow rays, balls for the rest; LDS only),
+// 4 = the same with the cone families' member sections left in global memory (large scenes).
 // LDSGEOM: the table the hot loop reads (screen table, or the doubles when SCREEN == 0) is staged in LDS.
 // EXACTLDS (SCREEN > 0 only): the exact doubles are staged in LDS as well, behind the screen table; otherwise the
 // rare exact tests read them from global memory.
@@ -42,7 +43,12 @@ namespace {
 template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
     if (LDSGEOM) {
-        if (SCREEN) {
+        if (SCREEN == 4) {
+            float *dst = (float *)ldsGeom;
+            for (int i = threadIdx.x; i < P.ldsHeadFloats; i += blockDim.x) dst[i] = P.geomF[i];
+            float *mem = dst + 4 * (size_t)P.ballMembersLds;
+            for (int i = threadIdx.x; i < P.ballMembersFloats; i += blockDim.x) mem[i] = P.geomF[P.ballMembersSrc + i];
+        } else if (SCREEN) {
             float *dst = (float *)ldsGeom;
             for (int i = threadIdx.x; i < P.filterFloats; i += blockDim.x) dst[i] = P.geomF[i];
             if (EXACTLDS) {
@@ -151,14 +157,14 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 if (SCREEN) {
                     const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
                     const bool tame = s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001;
-                    if (tame && (SCREEN == 1 || s1 < (SCREEN == 3 ? P.familyScale : 1e5))) {
+                    if (tame && (SCREEN == 1 || s1 < (SCREEN >= 3 ? P.familyScale : 1e5))) {
                         const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
-                        if (SCREEN == 3) {
+                        if (SCREEN >= 3) {
                             // which fixed point the ray's line passes through decides the table it is screened with
                             int family = P.ballFamily;
                             if (mode == M_SHADOW) family = P.lightFamilyBase + li;
                             else if ((mode == M_INDEX || depth == 0) && P.cameraFamily >= 0) family = P.cameraFamily;
-                            closestHitFamilies<AVOID, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, family, negThreshold, h);
+                            closestHitFamilies<AVOID, EXACTLDS, SCREEN == 4>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, family, negThreshold, h);
                         } else if (SCREEN == 2) closestHitGrouped<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
                         else closestHitScreened<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
                     } else {  // exact loop over the doubles in global memory
@@ -440,7 +446,8 @@ TraceFn pickKernelA(bool lds, int screen, bool exactLds) {
     if (screen == 0) return traceKernel<A, true, 0, false, false>;
     if (screen == 1) return exactLds ? traceKernel<A, true, 1, true, false> : traceKernel<A, true, 1, false, false>;
     if (screen == 2) return exactLds ? traceKernel<A, true, 2, true, false> : traceKernel<A, true, 2, false, false>;
-    return exactLds ? traceKernel<A, true, 3, true, false> : traceKernel<A, true, 3, false, false>;
+    if (screen == 3) return exactLds ? traceKernel<A, true, 3, true, false> : traceKernel<A, true, 3, false, false>;
+    return traceKernel<A, true, 4, false, false>;
 }
 
 // Scenes with a transparent shape run the tree-walk kernels, built only for the general avoid mode, screen
@@ -459,7 +466,7 @@ TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool tran
 struct GraftJob {
     TraceParams P;
     int avoidMode;
-    int screen;   // 0 = exact only, 1 = screen per sphere, 2 = two-level ball screen, 3 = per-family two-level screens
+    int screen;   // 0 = exact only, 1 = screen per sphere, 2 = two-level ball screen, 3/4 = per-family two-level screens
     bool lds;
     bool exactLds;  // exact doubles staged in LDS behind the screen table
     bool transp;    // some shape is transparent: tree-walk kernel
@@ -493,7 +500,7 @@ GRAFT_API int graftInit(int device) {
     gNumCU = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&gStream, hipStreamNonBlocking));
     for (int a = 0; a < 3; ++a)
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < 5; ++f)
             for (int x = 0; x < 2; ++x)
                 for (int t = 0; t < 2; ++t)
                     HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f, x != 0, t != 0),
@@ -670,7 +677,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     // only, 1 = single-precision screen per sphere, 2 = two-level ball screen, 3 (default) = per-family two-level
     // screens; each level is used only where the scene qualifies for it
     const char *env = getenv("GRAFT_SCREEN");
-    const int screenCap = env && env[0] >= '0' && env[0] <= '3' ? env[0] - '0' : 3;
+    const int screenCap = env && env[0] >= '0' && env[0] <= '4' ? env[0] - '0' : 4;
     int screen = (screenCap >= 1 && !sph.empty()) ? 1 : 0;
     if (transparent) avoidMode = 2;  // the tree-walk kernels exist for the general avoid mode only
     std::vector<float> tableF;
@@ -705,8 +712,21 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
             std::vector<float> inter;
             std::vector<int> interShape;
             interleaveFamilies(fam, inter, interShape);
+            const size_t headFloats = 4 * (size_t)balls.memberBase * fam.size();
+            const size_t ballMemberFloats = balls.entries.size() - 4 * (size_t)balls.memberBase;
             if (sizeof(float) * inter.size() <= kLdsMax) {
                 screen = 3;
+            } else if (screenCap >= 4 && sizeof(float) * (headFloats + ballMemberFloats) <= kLdsMax) {
+                // cone member sections stay in global memory; the ball family's member section is appended to the
+                // table so that the kernel can stage it behind the group sections
+                screen = 4;
+                P.ldsHeadFloats = (int)headFloats;
+                P.ballMembersLds = (int)(headFloats / 4);
+                P.ballMembersSrc = (int)inter.size();
+                P.ballMembersFloats = (int)ballMemberFloats;
+                inter.insert(inter.end(), balls.entries.begin() + 4 * (size_t)balls.memberBase, balls.entries.end());
+            }
+            if (screen >= 3) {
                 tableF.swap(inter);
                 memberShape.swap(interShape);
                 P.families = (int)fam.size();
@@ -771,11 +791,13 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     job->avoidMode = avoidMode;
     job->blocksPerCU = 0;
     job->screen = screen;
-    const size_t tableBytes = screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)P.geomDoubles;
+    const size_t tableBytes = screen == 4 ? sizeof(float) * ((size_t)P.ldsHeadFloats + P.ballMembersFloats)
+                            : screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)P.geomDoubles;
     const size_t exactBytes = sizeof(double) * (size_t)P.geomDoubles;
     job->lds = tableBytes <= kLdsMax;
     job->transp = transparent;
-    job->exactLds = !transparent && job->lds && screen && ((tableBytes + 31) & ~(size_t)31) + exactBytes <= kLdsMax;
+    job->exactLds = !transparent && job->lds && screen && screen != 4 &&
+                    ((tableBytes + 31) & ~(size_t)31) + exactBytes <= kLdsMax;
     P.exactLdsOffset = (int)((tableBytes + 31) & ~(size_t)31);
     job->ldsBytes = !job->lds ? 0 : job->exactLds ? P.exactLdsOffset + exactBytes : tableBytes;
     // workgroup size: as many workgroups per CU as the LDS footprint allows, 16 waves per CU in every case

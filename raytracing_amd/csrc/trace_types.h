@@ -61,6 +61,9 @@ struct TraceParams {
     // per-family screen (SCREEN == 3): `families` interleaved two-level tables; cone families first, ball table last
     int families, ballFamily, cameraFamily, lightFamilyBase;  // cameraFamily < 0: primary rays use the ball table
     double familyScale;        // rays whose |origin|_1 exceeds this use the exact loop
+    // SCREEN == 4 (cone member sections stay in global memory): LDS holds the first ldsHeadFloats floats of geomF
+    // (all group sections) and then the ball family's member section, copied from geomF + ballMembersSrc (floats)
+    int ldsHeadFloats, ballMembersLds /* float4 index in LDS */, ballMembersSrc, ballMembersFloats;
     const int *memberShape;    // grouped screen: shape index of every member-table entry, -1 = padding
     const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
     const double *geom;
