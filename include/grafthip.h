@@ -146,6 +146,11 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
 
 GRAFT_API void graftJobDestroy(GraftJob *job);
 
+/* Which screen the job's kernels use in front of the exact sphere test (diagnostics; no reference counterpart):
+ * 0 = none (exact double loop), 1 = single-precision screen per sphere, 2 = two-level ball screen, 3 = two-level
+ * screens per ray family, 4 = the same with cone member sections in global memory.  -1 for a null job. */
+GRAFT_API int graftJobScreenLevel(const GraftJob *job);
+
 /* Trace loop rows [row0, row0+nRows) of the job's frame into DEVICE memory: `frame` holds nRows*nCols pixels
  * of `format`, row-major in iy then ix; `hitIndex` (optional, may be NULL) nRows*nCols int32 closest-shape
  * indices (-1 = miss) of each pixel's first primary ray (the mask of rayIntersect, mainTracing.c:157, over

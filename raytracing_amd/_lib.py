@@ -77,6 +77,7 @@ lib.graftJobCreate.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTER(GraftV
                                ctypes.POINTER(ctypes.c_void_p)]
 lib.graftJobDestroy.argtypes = [ctypes.c_void_p]
 lib.graftJobDestroy.restype = None
+lib.graftJobScreenLevel.argtypes = [ctypes.c_void_p]
 lib.graftJobTrace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 lib.graftSynchronize.restype = ctypes.c_int

@@ -806,6 +806,8 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     return GRAFT_OK;
 }
 
+GRAFT_API int graftJobScreenLevel(const GraftJob *job) { return job ? job->screen : -1; }
+
 GRAFT_API void graftJobDestroy(GraftJob *job) {
     if (!job) return;
     if (gStream) (void)hipStreamSynchronize(gStream);

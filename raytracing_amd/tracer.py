@@ -165,6 +165,10 @@ class Job:
                                 ctypes.c_void_p(hit_index_ptr or 0), ctypes.c_void_p(counters_ptr or 0),
                                 ctypes.c_void_p(stream or 0)))
 
+    def screen_level(self):
+        # 0..4: which screen sits in front of the exact sphere test (graftJobScreenLevel)
+        return lib.graftJobScreenLevel(self._h)
+
     def close(self):
         if self._h:
             lib.graftJobDestroy(self._h)

@@ -1,0 +1,163 @@
+"""The conservative screens (single-precision per-sphere screen, two-level ball screen, per-family cone screens)
+must never change a result.  Random and adversarial sphere scenes, GPU against the CPU oracle, bit for bit, at
+every screen level (GRAFT_SCREEN = 0..4 caps the level a job may use; 0 is the plain double-precision loop)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from raytracing_amd import scenes
+from raytracing_amd.tracer import (ANTIALIASING_OFF, ANTIALIASING_ON, GRAFT_OUT_F64_RGB, ORTHOGRAPHIC, PERSPECTIVE,
+                                   Light, RayTracer, lightInit, lightSetAvoid)
+
+pytestmark = pytest.mark.gpu
+
+
+def scene(seed, n, size=(64, 64), lights=3, radius=(5.0, 40.0), box=400.0, refl=0.0, depth=4, projection=PERSPECTIVE,
+          passes=0, centre=(0.0, 0.0, 100.0)):
+    rng = scenes.SplitMix64(0xC0DE0000 + seed)
+    rt = RayTracer(*size)
+    for k in range(n):
+        c = [centre[0] + rng.uniform(-box, box), centre[1] + rng.uniform(-box, box), centre[2] + rng.uniform(-box, box)]
+        r = rng.uniform(*radius)
+        rt.sphereSetup(r, c, k, [rng.uniform(.1, 1), rng.uniform(.1, 1), rng.uniform(.1, 1)],
+                       refl if rng.uniform(0, 1) < 0.5 else 0.0, rng.uniform(0, .2), 1.0, 0.0)
+    rt.numShapes = n
+    for i in range(lights):
+        l = Light()
+        lightInit(l, [rng.uniform(.5, 1.5)] * 3, [rng.uniform(-300, 300), rng.uniform(-300, 300), rng.uniform(-200, 300)])
+        rt.lights.append(l)
+    rt.numLights = lights
+    rt.maxDepth, rt.projectionType = depth, projection
+    rt.aliasing, rt.numPasses = (ANTIALIASING_ON, passes) if passes else (ANTIALIASING_OFF, 1)
+    rt.sceneInitialize([0, 0, 0], 256, 1000)
+    return rt
+
+
+def check_all_levels(rt, levels=(0, 1, 2, 3, 4)):
+    want = ob.render(rt, threads=16, want_index=True)
+    old = os.environ.get("GRAFT_SCREEN")
+    try:
+        for level in levels:
+            os.environ["GRAFT_SCREEN"] = str(level)
+            rgb, idx = rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_index=True)
+            assert np.array_equal(idx, want["index"]), "index mask differs at screen level %d" % level
+            assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64)), \
+                "RGB differs at screen level %d (max abs %g)" % (level, np.nanmax(np.abs(rgb - want["rgb"])))
+    finally:
+        if old is None:
+            os.environ.pop("GRAFT_SCREEN", None)
+        else:
+            os.environ["GRAFT_SCREEN"] = old
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_scenes(gpu, seed):
+    check_all_levels(scene(seed, 96 + 40 * seed, refl=0.6, depth=5))
+
+
+def test_supersampled_and_orthographic(gpu):
+    check_all_levels(scene(10, 150, passes=3, size=(48, 48)))
+    check_all_levels(scene(11, 130, projection=ORTHOGRAPHIC))  # no camera family: primary rays use the ball table
+
+
+def test_rotated_zoomed_view(gpu):
+    rt = scene(12, 160, refl=0.4)
+    rt.rotateView(0.4, [0.0, 1.0, 0.0])
+    rt.rotateView(-0.25, list(rt.lrVec))
+    rt.screenWidth *= 1.1
+    rt.screenHeight *= 0.9
+    check_all_levels(rt)
+
+
+def test_lights_and_camera_inside_spheres(gpu):
+    """Apex inside a sphere: every line through it meets that sphere, the cone entry must always pass."""
+    rt = scene(13, 100)
+    rt.sphereSetup(90, list(rt.lights[0].loc), 100, [.8, .3, .3], 0.0, 0.1, 1.0, 0.0)          # around light 0
+    rt.sphereSetup(2000, [0, 0, -1256 + 10], 101, [.3, .8, .3], 0.3, 0.1, 1.0, 0.0)             # around the camera
+    rt.sphereSetup(60, [rt.lights[1].loc[0] + 60.0, rt.lights[1].loc[1], rt.lights[1].loc[2]], 102, [.3, .3, .8], 0.0,
+                   0.1, 1.0, 0.0)                                                                # light 1 ON its surface
+    rt.numShapes = 103
+    check_all_levels(rt)
+
+
+def test_avoid_lists(gpu):
+    rt = scene(14, 120, lights=3)
+    lightSetAvoid(rt.lights[0], [rt.shapes[5]], 1)
+    check_all_levels(rt)                       # avoid mode 1 (one shape per light)
+    lightSetAvoid(rt.lights[1], [rt.shapes[7], rt.shapes[70], rt.shapes[7]], 3)
+    check_all_levels(rt)                       # avoid mode 2 (general mask)
+
+
+def test_duplicate_and_concentric_spheres_break_ties_by_index(gpu):
+    """Equal distances: the reference keeps the lowest index.  The two-level screens visit spheres out of order."""
+    rt = scene(15, 80)
+    for k in range(40):
+        src = rt.shapes[k]
+        rt.sphereSetup(src.unif[3], src.unif[0:3], 80 + k, [.9, .1, .1], 0.0, 0.1, 1.0, 0.0)   # exact duplicates
+    rt.numShapes = 120
+    check_all_levels(rt)
+    idx = rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_index=True)[1]
+    assert idx.max() < 80 and (idx >= 0).any()  # a duplicate never wins over its lower-indexed original
+
+
+def test_tiny_giant_and_far_spheres(gpu):
+    rt = scene(16, 90, radius=(0.01, 3.0))
+    rt.sphereSetup(5000, [0, 0, 200], 90, [.5, .5, .9], 0.2, 0.1, 1.0, 0.0)      # encloses everything
+    rt.sphereSetup(1e-3, [10, 10, 50], 91, [1, 1, 1], 0.0, 0.1, 1.0, 0.0)
+    rt.numShapes = 92
+    check_all_levels(rt)
+
+
+def test_large_coordinates_fall_back(gpu):
+    """Coordinates beyond 1e5 disable the two-level screens, beyond 1e15 the per-sphere screen; results stay exact."""
+    rt = scene(17, 100, centre=(3e5, -2e5, 1e5), box=300.0)
+    rt.sceneInitialize([3e5, -2e5, 1e5], 256, 1000)
+    for l in rt.lights[:rt.numLights]:
+        l.loc = [l.loc[0] + 3e5, l.loc[1] - 2e5, l.loc[2] + 1e5]
+    check_all_levels(rt)
+    rt = scene(18, 70)
+    rt.sphereSetup(1e15, [0, 0, 3e16], 70, [.2, .9, .4], 0.0, 0.1, 1.0, 0.0)
+    rt.numShapes = 71
+    check_all_levels(rt)
+
+
+def test_many_lights(gpu):
+    check_all_levels(scene(19, 100, lights=7))
+    check_all_levels(scene(20, 100, lights=9))  # more families than the cone tables support: ball screen
+
+
+def test_transparent_with_many_spheres(gpu):
+    rt = scene(21, 90, refl=0.5, depth=5)
+    for k in (3, 17, 40, 41):
+        rt.shapes[k].transparency = 0.7
+        rt.shapes[k].refrIndex = 1.3 + 0.01 * k
+    check_all_levels(rt)
+
+
+def test_levels_are_actually_used(gpu):
+    """The scenes above must really reach the screens they are meant to test."""
+    def level(rt, cap=None):
+        old = os.environ.pop("GRAFT_SCREEN", None)
+        try:
+            if cap is not None:
+                os.environ["GRAFT_SCREEN"] = str(cap)
+            job = rt.create_job()
+            lv = job.screen_level()
+            job.close()
+            return lv
+        finally:
+            os.environ.pop("GRAFT_SCREEN", None)
+            if old is not None:
+                os.environ["GRAFT_SCREEN"] = old
+    assert level(scene(0, 96)) == 3
+    assert [level(scene(0, 96), cap) for cap in (0, 1, 2, 3)] == [0, 1, 2, 3]
+    assert level(scenes.workload("cfg4", 64, 64)) == 3 and level(scenes.workload("cfg3", 64, 64)) == 3
+    assert level(scenes.workload("cfg5", 64, 64)) == 4
+    assert level(scene(20, 100, lights=9)) == 2          # too many lights for the family tables
+    assert level(scene(1, 40)) == 1                      # too few spheres for grouping
+    assert level(scenes.default_scene()) == 1            # planes: per-sphere screen only
+    rt = scene(21, 90)
+    rt.shapes[3].transparency = 0.5
+    assert level(rt) == 1                                # transparent: tree-walk kernels, per-sphere screen
