@@ -3,9 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg5|default|single]
 
-One step = one whole frame of the workload: every rank traces its band of rows with the HIP kernel
-(inputs -- packed scene, loop-offset tables -- already resident in HBM) into a float4 framebuffer and, for
-N > 1, the bands are gathered into rank 0's HBM with one RCCL gather.  Prints ONE JSON line on rank 0.
+One step = one whole frame of the workload: every rank traces its rows with the HIP kernel
+(inputs -- packed scene, loop-offset tables -- already resident in HBM) into a float4 framebuffer; for
+N > 1 the rows are dealt to the ranks in pieces and every piece is sent to rank 0's HBM over RCCL while the next one
+is being traced.  Prints ONE JSON line on rank 0.
 
 metric  Mrays/s, ray = one closest-hit query (primary + shadow + reflection; rayIntersectAvoid of the
         reference, mainTracing.c:128), counted by the kernel itself in an untimed pass.
@@ -31,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 import raytracing_amd  # noqa: E402
 from raytracing_amd import scenes  # noqa: E402
-from raytracing_amd.distributed import band_rows, trace_and_gather  # noqa: E402
+from raytracing_amd.distributed import local_rows, trace_and_gather  # noqa: E402
 from raytracing_amd.tracer import GRAFT_OUT_F32_RGBA  # noqa: E402
 
 FLOP_PER_TEST = 17            # FP64 flops of one ray-sphere test on the miss path (shapes.c:52-54)
@@ -134,7 +135,7 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-frame512", action="store_true")
-    ap.add_argument("--chunks", type=int, default=8, help="pieces per band in the trace/gather pipeline (N > 1)")
+    ap.add_argument("--chunks", type=int, default=8, help="pieces per GPU in the trace/gather pipeline (N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,13 +153,12 @@ def main():
     rt, desc = build_workload(args.workload, args.width, args.height)
     job = rt.create_job()
     W, H = job.nCols, job.nRows
-    row0, n_rows = band_rows(H, world, rank)
+    row0, n_rows = 0, H
     if rank == 0:  # rank 0 owns the assembled frame and traces straight into its own rows of it
-        frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
-        band = frame[row0:row0 + n_rows]
-    else:
+        frame = band = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    else:          # the other ranks trace their pieces into a buffer of their own and send them to rank 0
         frame = None
-        band = torch.empty((n_rows, W, 4), dtype=torch.float32, device=dev)
+        band = torch.empty((local_rows(H, world, rank, args.chunks), W, 4), dtype=torch.float32, device=dev)
     counters = torch.zeros(2, dtype=torch.int64, device=dev)
     # a real (non-null) stream: kernels, events and the RCCL transfers of the gather are all ordered on it
     torch_stream = torch.cuda.Stream(device=dev)
@@ -216,7 +216,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "config": {"workload": desc, "frame": [W, H], "output": "float4 RGBA in HBM",
-                                            "parallelism": "row bands x%d%s" % (world, (" + RCCL gather to rank 0, pipelined in %d pieces" % args.chunks) if world > 1 else "")},
+                                            "parallelism": ("1 GPU" if world == 1 else "rows dealt round-robin in %d pieces per GPU x%d, "
+                                                            "RCCL send/recv to rank 0 pipelined behind tracing"
+                                                            % (args.chunks, world))},
             "rays_per_frame": rays, "tests_per_frame": tests,
             "primary_Msamples_per_s": W * H * (rt.numPasses ** 2 if rt.aliasing else 1) / (elapsed / args.steps) / 1e6,
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU, "unit": "TFLOP/s",
@@ -227,6 +229,17 @@ def main():
                                  "(ray, shape) pair; the kernel proves most pairs to be misses with cheaper "
                                  "single-precision screens, so achieved can exceed the FP64 peak"},
         }
+        if world > 1:  # the assembled frame against rank 0's own trace of 16 tile rows spread over all pieces
+            torch.cuda.synchronize()
+            check = torch.empty((8, W, 4), dtype=torch.float32, device=dev)
+            same = True
+            for i in range(16):
+                r = min(int((i + 0.5) * H / 16) // 8 * 8, max(H - 8, 0))
+                n = min(8, H - r)
+                job.trace(r, n, GRAFT_OUT_F32_RGBA, check.data_ptr(), None, None, stream)
+                torch.cuda.synchronize()
+                same = same and bool(torch.equal(check[:n], frame[r:r + n]))
+            out["gathered_frame_matches_local_trace"] = same
         if world == 1 and not args.no_frame512:
             out["frame_512"] = frame_512(dev)
         if world == 1 and not args.no_cpu:

@@ -1,11 +1,16 @@
-"""Row-band sharding of one frame over the GPUs of a node (one process per GPU, torch.distributed).
+"""Row sharding of one frame over the GPUs of a node (one process per GPU, torch.distributed).
 
-Pixels are independent and the scene is tiny, so every rank holds the whole packed scene and traces a
-contiguous band of loop rows; the frame is row-major in y, so a band is one contiguous block.  The only
-exchange is the assembly of the frame in rank 0's memory: every other rank sends its band straight to
-rank 0 (a grouped send/recv, which is how RCCL implements a gather; on the xGMI mesh each sender has its
-own link to the root, so the transfers run concurrently).  Rank 0 traces directly into its rows of the
-frame and sends nothing.
+Pixels are independent and the scene is tiny, so every rank holds the whole packed scene and traces rows of the
+frame; the frame is row-major in y, so a run of rows is one contiguous block.  The only exchange is the assembly of
+the frame in rank 0's memory: every other rank sends its rows straight to rank 0 (grouped send/recv, which is how
+RCCL implements a gather; on the xGMI mesh each sender has its own link to the root, so the transfers run
+concurrently).  Rank 0 traces directly into its rows of the frame and sends nothing.
+
+Two decompositions: `band_rows` (one contiguous band per rank, `gather_bands`) and `frame_pieces` (the frame cut
+into world x chunks pieces dealt round-robin, `trace_and_gather`).  The second is what bench.py uses: rows differ in
+cost (how many spheres their rays see), and dealing pieces of every part of the frame to every rank evens that out
+(ray counts of the 1024-sphere workload on 8 ranks: largest contiguous band 11 % above the mean, round-robin 3 %),
+while each piece's transfer overlaps the tracing of the next.
 """
 import torch.distributed as dist
 
@@ -63,37 +68,60 @@ def chunk_rows(start, count, chunks):
     return out
 
 
-def trace_and_gather(trace, band, frame, n_rows, world, rank, chunks=8, group=None):
-    """One frame: trace this rank's band piece by piece and ship every finished piece to rank 0 while the next one
-    is being traced.  `trace(first_row, rows, tensor)` must queue the kernel that fills `tensor` (the piece's
-    [rows][cols][channels] view) on the current stream.  The transfers are queued behind the piece's kernel (RCCL
-    waits for the current stream at the time of the call) and only waited for at the end of the frame, so on a
-    strong-scaled frame the exchange hides behind the tracing of the later pieces.  Every rank cuts every band the
-    same way, so sends and receives pair up in order."""
-    start, count = band_rows(n_rows, world, rank)
-    works = []
+def frame_pieces(n_rows, world, chunks):
+    """Cut rows [0, n_rows) into at most world*chunks tile-aligned pieces of near-equal size, dealt round-robin:
+    list of (first row, rows, owner rank), in row order.  Every rank computes the same list."""
+    tiles = (n_rows + TILE_ROWS - 1) // TILE_ROWS
+    count = max(1, min(world * max(1, chunks), tiles))
+    out = []
+    for k in range(count):
+        r0 = (k * tiles // count) * TILE_ROWS
+        r1 = min(((k + 1) * tiles // count) * TILE_ROWS, n_rows)
+        if r1 > r0:
+            out.append((r0, r1 - r0, k % world))
+    return out
+
+
+def owned_pieces(n_rows, world, rank, chunks):
+    """This rank's pieces: list of (first row, rows, first row in the rank's own buffer)."""
+    out, at = [], 0
+    for r0, n, owner in frame_pieces(n_rows, world, chunks):
+        if owner == rank:
+            out.append((r0, n, at))
+            at += n
+    return out
+
+
+def local_rows(n_rows, world, rank, chunks):
+    """Rows of the buffer a rank needs for its pieces (rank 0 needs none: it traces into the frame)."""
+    return sum(n for _, n, _ in owned_pieces(n_rows, world, rank, chunks))
+
+
+def trace_and_gather(trace, local, frame, n_rows, world, rank, chunks=8, group=None):
+    """One frame: trace this rank's pieces one by one and ship every finished piece to rank 0 while the next one is
+    being traced.  `trace(first_row, rows, tensor)` must queue the kernel that fills `tensor` (the piece's
+    [rows][cols][channels] view) on the current stream.  `local` is this rank's [local_rows][cols][channels] buffer
+    (ignored on rank 0, which traces into `frame`, the whole [n_rows][cols][channels] tensor).  The transfers are
+    queued behind the piece's kernel (RCCL waits for the current stream at the time of the call) and only waited
+    for at the end of the frame, so on a strong-scaled frame the exchange hides behind the tracing of the later
+    pieces.  Every rank derives the same piece list, so sends and receives pair up in order."""
     if world == 1:
-        for r0, n in chunk_rows(start, count, 1):
-            trace(r0, n, band[r0 - start:r0 - start + n])
-        if frame is not None and band.data_ptr() != frame.data_ptr():
-            frame[:count].copy_(band)
+        trace(0, n_rows, frame)
         return
-    mine = chunk_rows(start, count, chunks)
-    others = {r: chunk_rows(*band_rows(n_rows, world, r), chunks) for r in range(1, world)} if rank == 0 else {}
-    rounds = max([len(mine)] + [len(v) for v in others.values()])
-    for c in range(rounds):
+    pieces = frame_pieces(n_rows, world, chunks)
+    mine = owned_pieces(n_rows, world, rank, chunks)
+    works = []
+    for c in range((len(pieces) + world - 1) // world):
         ops = []
         if c < len(mine):
-            r0, n = mine[c]
-            piece = band[r0 - start:r0 - start + n]
+            r0, n, at = mine[c]
+            piece = frame[r0:r0 + n] if rank == 0 else local[at:at + n]
             trace(r0, n, piece)
             if rank != 0:
                 ops.append(dist.P2POp(dist.isend, piece, 0, group))
         if rank == 0:
-            for r, pieces in others.items():
-                if c < len(pieces):
-                    r0, n = pieces[c]
-                    ops.append(dist.P2POp(dist.irecv, frame[r0:r0 + n], r, group))
+            for r0, n, owner in pieces[c * world + 1:(c + 1) * world]:
+                ops.append(dist.P2POp(dist.irecv, frame[r0:r0 + n], owner, group))
         if ops:
             works.extend(dist.batch_isend_irecv(ops))
     for w in works:

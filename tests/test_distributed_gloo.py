@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from raytracing_amd.distributed import band_rows, chunk_rows, gather_bands, trace_and_gather
+from raytracing_amd.distributed import (band_rows, chunk_rows, frame_pieces, gather_bands, local_rows, owned_pieces,
+                                        trace_and_gather)
 
 
 def _free_port():
@@ -58,9 +59,9 @@ def _pipeline_worker(rank, world, port, n_rows, n_cols, chunks, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        start, count = band_rows(n_rows, world, rank)
+        count = sum(n for _, n, _ in owned_pieces(n_rows, world, rank, chunks))
         frame = torch.full((n_rows, n_cols, 4), -1.0) if rank == 0 else None
-        band = frame[start:start + count] if rank == 0 else torch.empty((count, n_cols, 4))
+        band = None if rank == 0 else torch.empty((local_rows(n_rows, world, rank, chunks), n_cols, 4))
         calls = []
 
         def trace(first, rows, piece):  # stands for the kernel launch: fills the piece's rows
@@ -81,7 +82,7 @@ def _pipeline_worker(rank, world, port, n_rows, n_cols, chunks, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_rows,chunks", [(2, 128, 4), (3, 100, 8), (2, 24, 8), (2, 8, 3)])
+@pytest.mark.parametrize("world,n_rows,chunks", [(2, 128, 4), (3, 100, 8), (2, 24, 8), (2, 8, 3), (3, 20, 1)])
 def test_trace_and_gather_pipeline(world, n_rows, chunks):
     port = _free_port()
     with mp.Manager() as m:
@@ -94,3 +95,16 @@ def test_chunk_rows():
     assert chunk_rows(0, 2048, 8) == [(i * 256, 256) for i in range(8)]
     assert chunk_rows(16, 20, 8) == [(16, 8), (24, 8), (32, 4)]
     assert chunk_rows(0, 0, 4) == [] and chunk_rows(8, 5, 4) == [(8, 5)]
+
+
+def test_frame_pieces():
+    for n_rows, world, chunks in [(16384, 8, 8), (100, 3, 8), (8, 2, 3), (20, 3, 1), (513, 4, 2), (1, 2, 2)]:
+        pieces = frame_pieces(n_rows, world, chunks)
+        assert pieces[0][0] == 0 and sum(n for _, n, _ in pieces) == n_rows
+        assert all(a[0] + a[1] == b[0] for a, b in zip(pieces, pieces[1:]))          # contiguous, in row order
+        assert all(r0 % 8 == 0 and n > 0 for r0, n, _ in pieces)
+        assert [o for _, _, o in pieces] == [k % world for k in range(len(pieces))]  # dealt round-robin
+        assert len(pieces) <= world * chunks
+        assert sum(local_rows(n_rows, world, r, chunks) for r in range(world)) == n_rows
+    assert frame_pieces(16384, 8, 8)[:2] == [(0, 256, 0), (256, 256, 1)]
+    assert owned_pieces(64, 2, 1, 2) == [(16, 16, 0), (48, 16, 16)]
