@@ -392,9 +392,14 @@ __device__ __forceinline__ void coneBlock(const float4v c0, const float4v c1, co
 // interleaved entry by entry (entry e of family f at float4 index e * families + f), so lanes of one wave may
 // follow different families at full LDS rate.  Spheres are met out of index order; see closestHitGrouped for
 // why the winner does not depend on it.
-// MEMBERS_GLOBAL: only the group sections of all families and the ball family's member section are staged in LDS
-// (scenes whose cone member sections do not fit); cone members are then read from the table in global memory.
-template <int AVOID, bool EXACTLDS, bool MEMBERS_GLOBAL>
+// SUPER (scenes whose member sections do not fit in LDS): only the group sections of all families, the ball
+// family's member section and the third-level sections are staged in LDS; cone members are read from the table in
+// global memory.  The walk has a third level on top: one entry per 8 consecutive groups (an enclosing cone, or
+// ball, of their 64 spheres, built like a group's), and only the groups of passing entries are looked at.  The
+// argument for skipping is the same as for a group: the entry encloses every member with the member's own margin.
+// (With lanes of one wave following different families the groups to open add up, which is why smaller scenes,
+// whose tables fit in LDS whole, keep the two-level walk: measured 34 vs 23 Grays/s on 1024 spheres.)
+template <int AVOID, bool EXACTLDS, bool SUPER>
 __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double sx, double sy, double sz, double dx,
                                                    double dy, double dz, int avoidShape, const unsigned char *avoidRow,
                                                    int family, float negThreshold, Hit &h) {
@@ -451,7 +456,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
 #ifdef GRAFT_STAMPS
                         if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
 #endif
-                        if (!MEMBERS_GLOBAL) {
+                        if (!SUPER) {
                             const float4v *mb = table + (size_t)(P.memberBase + (j + u) * 8) * F;
                             members4(mb, F, (j + u) * 8);
                             members4(mb + 4 * F, F, (j + u) * 8 + 4);
@@ -468,13 +473,44 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                 }
             }
         };
-        float4v a0 = table[0], a1 = table[F], a2 = table[2 * F], a3 = table[3 * F];
-        for (int j = 0; j < P.groupEntries; j += 8) {
-            const float4v *nb = table + (size_t)(j + 4) * F;
-            const float4v b0 = nb[0], b1 = nb[F], b2 = nb[2 * F], b3 = nb[3 * F];
-            groups4(a0, a1, a2, a3, j);
-            a0 = nb[4 * F]; a1 = nb[5 * F]; a2 = nb[6 * F]; a3 = nb[7 * F];
-            groups4(b0, b1, b2, b3, j + 4);
+        if (!SUPER) {  // two levels: scan every group entry
+            float4v a0 = table[0], a1 = table[F], a2 = table[2 * F], a3 = table[3 * F];
+            for (int j = 0; j < P.groupEntries; j += 8) {
+                const float4v *nb = table + (size_t)(j + 4) * F;
+                const float4v b0 = nb[0], b1 = nb[F], b2 = nb[2 * F], b3 = nb[3 * F];
+                groups4(a0, a1, a2, a3, j);
+                a0 = nb[4 * F]; a1 = nb[5 * F]; a2 = nb[6 * F]; a3 = nb[7 * F];
+                groups4(b0, b1, b2, b3, j + 4);
+            }
+        } else {  // three levels: scan the entries that stand for 8 groups each; open the groups of those that pass
+            const float4v *sup = (const float4v *)ldsGeom + P.superLds + family;
+            auto supers4 = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j) {
+                float e0, e1, e2, e3;
+                evaluate(c0, c1, c2, c3, e0, e1, e2, e3);
+                const float best = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
+                if (!(best < limit)) {
+#pragma nounroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float eu = u == 0 ? e0 : u == 1 ? e1 : u == 2 ? e2 : e3;
+                        if (!(eu < limit)) {
+#pragma nounroll
+                            for (int half = 0; half < 2; ++half) {
+                                const int g0 = (j + u) * 8 + 4 * half;
+                                const float4v *gb = table + (size_t)g0 * F;
+                                groups4(gb[0], gb[F], gb[2 * F], gb[3 * F], g0);
+                            }
+                        }
+                    }
+                }
+            };
+            float4v a0 = sup[0], a1 = sup[F], a2 = sup[2 * F], a3 = sup[3 * F];
+            for (int j = 0; j < P.superEntries; j += 8) {
+                const float4v *nb = sup + (size_t)(j + 4) * F;
+                const float4v b0 = nb[0], b1 = nb[F], b2 = nb[2 * F], b3 = nb[3 * F];
+                supers4(a0, a1, a2, a3, j);
+                a0 = nb[4 * F]; a1 = nb[5 * F]; a2 = nb[6 * F]; a3 = nb[7 * F];
+                supers4(b0, b1, b2, b3, j + 4);
+            }
         }
     };
     if (family != P.ballFamily) walk(std::true_type{});

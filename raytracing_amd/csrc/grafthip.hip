@@ -34,7 +34,8 @@ namespace {
 
 // SCREEN: 0 = exact double loop, 1 = single-precision screen per sphere, 2 = two-level ball screen,
 // 3 = two-level screens per ray family (cones for primary and shadow rays, balls for the rest; LDS only),
-// 4 = the same with the cone families' member sections left in global memory (large scenes).
+// 4 = large scenes: three-level screens per ray family (an entry per 8 groups on top), the cone families' member
+//     sections left in global memory.
 // LDSGEOM: the table the hot loop reads (screen table, or the doubles when SCREEN == 0) is staged in LDS.
 // EXACTLDS (SCREEN > 0 only): the exact doubles are staged in LDS as well, behind the screen table; otherwise the
 // rare exact tests read them from global memory.
@@ -46,8 +47,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         if (SCREEN == 4) {
             float *dst = (float *)ldsGeom;
             for (int i = threadIdx.x; i < P.ldsHeadFloats; i += blockDim.x) dst[i] = P.geomF[i];
-            float *mem = dst + 4 * (size_t)P.ballMembersLds;
-            for (int i = threadIdx.x; i < P.ballMembersFloats; i += blockDim.x) mem[i] = P.geomF[P.ballMembersSrc + i];
+            float *tail = dst + 4 * (size_t)P.ballMembersLds;
+            for (int i = threadIdx.x; i < P.ldsTailFloats; i += blockDim.x) tail[i] = P.geomF[P.ldsTailSrc + i];
         } else if (SCREEN) {
             float *dst = (float *)ldsGeom;
             for (int i = threadIdx.x; i < P.filterFloats; i += blockDim.x) dst[i] = P.geomF[i];
@@ -714,17 +715,22 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
             interleaveFamilies(fam, inter, interShape);
             const size_t headFloats = 4 * (size_t)balls.memberBase * fam.size();
             const size_t ballMemberFloats = balls.entries.size() - 4 * (size_t)balls.memberBase;
+            std::vector<float> supers;
+            interleaveSupers(fam, supers);
             if (sizeof(float) * inter.size() <= kLdsMax) {
                 screen = 3;
-            } else if (screenCap >= 4 && sizeof(float) * (headFloats + ballMemberFloats) <= kLdsMax) {
-                // cone member sections stay in global memory; the ball family's member section is appended to the
-                // table so that the kernel can stage it behind the group sections
+            } else if (screenCap >= 4 && sizeof(float) * (headFloats + ballMemberFloats + supers.size()) <= kLdsMax) {
+                // cone member sections stay in global memory; the ball family's member section and the third-level
+                // sections are appended to the table so that the kernel can stage them behind the group sections
                 screen = 4;
                 P.ldsHeadFloats = (int)headFloats;
                 P.ballMembersLds = (int)(headFloats / 4);
-                P.ballMembersSrc = (int)inter.size();
-                P.ballMembersFloats = (int)ballMemberFloats;
+                P.ldsTailSrc = (int)inter.size();
+                P.ldsTailFloats = (int)(ballMemberFloats + supers.size());
+                P.superLds = (int)((headFloats + ballMemberFloats) / 4);
+                P.superEntries = balls.superEntries;
                 inter.insert(inter.end(), balls.entries.begin() + 4 * (size_t)balls.memberBase, balls.entries.end());
+                inter.insert(inter.end(), supers.begin(), supers.end());
             }
             if (screen >= 3) {
                 tableF.swap(inter);
@@ -791,7 +797,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     job->avoidMode = avoidMode;
     job->blocksPerCU = 0;
     job->screen = screen;
-    const size_t tableBytes = screen == 4 ? sizeof(float) * ((size_t)P.ldsHeadFloats + P.ballMembersFloats)
+    const size_t tableBytes = screen == 4 ? sizeof(float) * ((size_t)P.ldsHeadFloats + P.ldsTailFloats)
                             : screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)P.geomDoubles;
     const size_t exactBytes = sizeof(double) * (size_t)P.geomDoubles;
     job->lds = tableBytes <= kLdsMax;

@@ -77,12 +77,14 @@ void putEntry(float *blk, int i, float cx, float cy, float cz, float rho) {
 }
 
 constexpr int kGroup = 8;          // spheres per group of the two-level screen
+constexpr int kSuper = 8;          // groups per entry of the third level
 constexpr double kGroupMargin = 0.1;
 constexpr double kGroupScale = 1e5;  // coordinates must stay below this for the margin to cover the rounding terms
 
-// Order of n points (3 doubles each) such that every run of kGroup consecutive points is a leaf of a k-d tree:
-// split the longest axis of the bounding box at the median (left part a multiple of kGroup) until at most kGroup
-// points remain; ties by index, so the result is deterministic.
+// Order of n points (3 doubles each) such that every run of kGroup consecutive points is a leaf of a k-d tree, and
+// every aligned run of kGroup * kSuper points a subtree: split the longest axis of the bounding box at the median
+// (left part a multiple of kGroup * kSuper while more than that many points remain, of kGroup below) until at most
+// kGroup points remain; ties by index, so the result is deterministic.
 inline std::vector<int> kdLeafOrder(const std::vector<double> &pts, int n) {
     std::vector<int> idx(n);
     for (int k = 0; k < n; ++k) idx[k] = k;
@@ -101,7 +103,8 @@ inline std::vector<int> kdLeafOrder(const std::vector<double> &pts, int n) {
         int axis = 0;
         for (int a = 1; a < 3; ++a)
             if (bhi[a] - blo[a] > bhi[axis] - blo[axis]) axis = a;
-        const int half = (count / 2 + kGroup - 1) / kGroup * kGroup;
+        const int unit = count > kGroup * kSuper ? kGroup * kSuper : kGroup;
+        const int half = (count / 2 + unit - 1) / unit * unit;
         std::sort(idx.begin() + seg.first, idx.begin() + seg.second, [&](int x, int y) {
             const double cx = pts[3 * (size_t)x + axis], cy = pts[3 * (size_t)y + axis];
             return cx < cy || (cx == cy && x < y);
@@ -118,10 +121,16 @@ inline std::vector<int> kdLeafOrder(const std::vector<double> &pts, int n) {
 struct TwoLevelTable {
     std::vector<float> entries;
     std::vector<int> memberShape;
-    int groupEntries = 0, memberBase = 0;
+    // third level: one entry per kSuper consecutive groups, padded to a multiple of 8 plus 8 entries (the scan fetches
+    // two blocks ahead), same packing
+    std::vector<float> supers;
+    int groupEntries = 0, memberBase = 0, superEntries = 0;
     void shape(int n, float neverPass) {
         const int nGroups = (n + kGroup - 1) / kGroup;
         groupEntries = (nGroups + 7) / 8 * 8;
+        superEntries = (groupEntries / kSuper + 7) / 8 * 8;
+        supers.assign(4 * (size_t)(superEntries + 8), 0.0f);
+        for (int i = 0; i < superEntries + 8; ++i) putEntry(supers.data() + 16 * (i / 4), i % 4, 0.0f, 0.0f, 0.0f, neverPass);
         memberBase = groupEntries + 8;
         const size_t total = (size_t)memberBase + (size_t)nGroups * kGroup + 8;
         entries.assign(4 * total, 0.0f);
@@ -129,6 +138,7 @@ struct TwoLevelTable {
         for (size_t i = 0; i < total; ++i) putEntry(entries.data() + 16 * (i / 4), (int)(i % 4), 0.0f, 0.0f, 0.0f, neverPass);
     }
     void group(int g, float x, float y, float z, float w) { putEntry(entries.data() + 16 * (g / 4), g % 4, x, y, z, w); }
+    void super(int s, float x, float y, float z, float w) { putEntry(supers.data() + 16 * (s / 4), s % 4, x, y, z, w); }
     void member(int g, int m, int shapeIndex, float x, float y, float z, float w) {
         const size_t e = (size_t)memberBase + (size_t)g * kGroup + m;
         putEntry(entries.data() + 16 * (e / 4), (int)(e % 4), x, y, z, w);
@@ -149,12 +159,10 @@ inline bool packBallTable(const std::vector<double> &sph, TwoLevelTable &T) {
     }
     const std::vector<int> order = kdLeafOrder(pts, n);
     T.shape(n, -INFINITY);  // rho = -inf never passes
-    const int nGroups = (n + kGroup - 1) / kGroup;
-    for (int gI = 0; gI < nGroups; ++gI) {
-        const int first = gI * kGroup, last = std::min(n, first + kGroup);
-        // centre of the bounding ball: start at the centroid and walk towards the farthest sphere with shrinking
-        // steps (Badoiu-Clarkson); any centre is valid, the radius below is what makes the ball enclose the members
-        double g[3] = {0, 0, 0};
+    // bounding ball of the spheres order[first..last): start at the centroid and walk towards the farthest sphere
+    // with shrinking steps (Badoiu-Clarkson); any centre is valid, the radius is what makes the ball enclose them
+    auto enclose = [&](int first, int last, double g[3], float &rho) {
+        g[0] = g[1] = g[2] = 0;
         for (int m = first; m < last; ++m)
             for (int a = 0; a < 3; ++a) g[a] += sph[4 * (size_t)order[m] + a] / (last - first);
         for (int it = 0; it < 64; ++it) {
@@ -176,8 +184,14 @@ inline bool packBallTable(const std::vector<double> &sph, TwoLevelTable &T) {
             R = fmax(R, sqrt(dx * dx + dy * dy + dz * dz) + sqrt(c[3]));
         }
         R = R * (1.0 + 1e-9) + kGroupMargin;
+        return screenRho(g, R * R * (1.0 + 1e-12), rho);
+    };
+    const int nGroups = (n + kGroup - 1) / kGroup;
+    for (int gI = 0; gI < nGroups; ++gI) {
+        const int first = gI * kGroup, last = std::min(n, first + kGroup);
+        double g[3];
         float rho;
-        if (!screenRho(g, R * R * (1.0 + 1e-12), rho)) return false;
+        if (!enclose(first, last, g, rho)) return false;
         T.group(gI, (float)g[0], (float)g[1], (float)g[2], rho);
         for (int m = first; m < last; ++m) {
             const int k = order[m];
@@ -185,6 +199,13 @@ inline bool packBallTable(const std::vector<double> &sph, TwoLevelTable &T) {
             if (!screenRho(c, c[3], rho)) return false;
             T.member(gI, m - first, k, (float)c[0], (float)c[1], (float)c[2], rho);
         }
+    }
+    for (int sI = 0; sI * kSuper < nGroups; ++sI) {
+        const int first = sI * kSuper * kGroup, last = std::min(n, first + kSuper * kGroup);
+        double g[3];
+        float rho;
+        if (!enclose(first, last, g, rho)) return false;
+        T.super(sI, (float)g[0], (float)g[1], (float)g[2], rho);
     }
     return true;
 }
@@ -242,10 +263,9 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
     };
     const std::vector<int> order = kdLeafOrder(dir, n);
     T.shape(n, -INFINITY);  // the table stores -kappa2: -inf never passes
-    const int nGroups = (n + kGroup - 1) / kGroup;
-    for (int gI = 0; gI < nGroups; ++gI) {
-        const int first = gI * kGroup, last = std::min(n, first + kGroup);
-        double a[3] = {0, 0, 0};
+    // enclosing cone of the spheres order[first..last): axis a, and -kappa2 of its half-angle
+    auto enclose = [&](int first, int last, double a[3]) -> float {
+        a[0] = a[1] = a[2] = 0;
         for (int m = first; m < last; ++m)
             for (int c = 0; c < 3; ++c) a[c] += dir[3 * (size_t)order[m] + c];
         auto normalise = [&]() {
@@ -269,12 +289,25 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
             theta = fmax(theta, angle(a, &dir[3 * (size_t)order[m]]) + alpha[order[m]]);
             nearest = fmin(nearest, dist[order[m]]);
         }
-        T.group(gI, (float)a[0], (float)a[1], (float)a[2], -kappa2(theta, nearest));
+        return -kappa2(theta, nearest);
+    };
+    const int nGroups = (n + kGroup - 1) / kGroup;
+    for (int gI = 0; gI < nGroups; ++gI) {
+        const int first = gI * kGroup, last = std::min(n, first + kGroup);
+        double a[3];
+        const float w = enclose(first, last, a);
+        T.group(gI, (float)a[0], (float)a[1], (float)a[2], w);
         for (int m = first; m < last; ++m) {
             const int k = order[m];
             T.member(gI, m - first, k, (float)dir[3 * (size_t)k], (float)dir[3 * (size_t)k + 1],
                      (float)dir[3 * (size_t)k + 2], -kappa2(alpha[k], dist[k]));
         }
+    }
+    for (int sI = 0; sI * kSuper < nGroups; ++sI) {
+        const int first = sI * kSuper * kGroup, last = std::min(n, first + kSuper * kGroup);
+        double a[3];
+        const float w = enclose(first, last, a);
+        T.super(sI, (float)a[0], (float)a[1], (float)a[2], w);
     }
 }
 
@@ -291,6 +324,15 @@ inline void interleaveFamilies(const std::vector<TwoLevelTable> &fam, std::vecto
             for (int c = 0; c < 4; ++c) entries[4 * (e * F + f) + c] = fam[f].entries[4 * e + c];
         for (size_t i = 0; i < members; ++i) memberShape[i * F + f] = fam[f].memberShape[i];
     }
+}
+
+// The same interleaving for the third-level sections: entry e of family f at float4 index e * families + f.
+inline void interleaveSupers(const std::vector<TwoLevelTable> &fam, std::vector<float> &entries) {
+    const size_t F = fam.size(), total = fam[0].supers.size() / 4;
+    entries.assign(4 * total * F, 0.0f);
+    for (size_t f = 0; f < F; ++f)
+        for (size_t e = 0; e < total; ++e)
+            for (int c = 0; c < 4; ++c) entries[4 * (e * F + f) + c] = fam[f].supers[4 * e + c];
 }
 
 }  // namespace graft

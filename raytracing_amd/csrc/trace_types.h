@@ -61,9 +61,12 @@ struct TraceParams {
     // per-family screen (SCREEN == 3): `families` interleaved two-level tables; cone families first, ball table last
     int families, ballFamily, cameraFamily, lightFamilyBase;  // cameraFamily < 0: primary rays use the ball table
     double familyScale;        // rays whose |origin|_1 exceeds this use the exact loop
-    // SCREEN == 4 (cone member sections stay in global memory): LDS holds the first ldsHeadFloats floats of geomF
-    // (all group sections) and then the ball family's member section, copied from geomF + ballMembersSrc (floats)
-    int ldsHeadFloats, ballMembersLds /* float4 index in LDS */, ballMembersSrc, ballMembersFloats;
+    // SCREEN == 4 (large scenes; three levels, cone member sections stay in global memory): LDS holds the first
+    // ldsHeadFloats floats of geomF (all group sections), then ldsTailFloats floats copied from geomF + ldsTailSrc:
+    // the ball family's member section (float4 index ballMembersLds) and the interleaved third-level sections
+    // (float4 index superLds, superEntries entries per family, a multiple of 8)
+    int ldsHeadFloats, ballMembersLds, ldsTailSrc, ldsTailFloats;
+    int superLds, superEntries;
     const int *memberShape;    // grouped screen: shape index of every member-table entry, -1 = padding
     const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
     const double *geom;

@@ -136,6 +136,26 @@ def test_transparent_with_many_spheres(gpu):
     check_all_levels(rt)
 
 
+def large_scene(seed, n, **kw):
+    """More spheres than the per-family tables can keep in LDS: the three-level walk (level 4)."""
+    rt = scene(seed, n, size=(48, 48), radius=(3.0, 14.0), **kw)
+    rt.sphereSetup(70, list(rt.lights[0].loc), n, [.8, .3, .3], 0.0, 0.1, 1.0, 0.0)              # around light 0
+    rt.sphereSetup(1500, [0, 0, -1256 + 10], n + 1, [.3, .8, .3], 0.3, 0.1, 1.0, 0.0)            # around the camera
+    for k in range(30):                                                                          # exact duplicates
+        src = rt.shapes[7 * k]
+        rt.sphereSetup(src.unif[3], src.unif[0:3], n + 2 + k, [.9, .1, .1], 0.0, 0.1, 1.0, 0.0)
+    rt.numShapes = n + 32
+    return rt
+
+
+def test_large_scenes_three_level_walk(gpu):
+    check_all_levels(large_scene(30, 1500, lights=5, refl=0.5, depth=3), levels=(0, 2, 4))
+    check_all_levels(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7, refl=0.5, depth=3), levels=(0, 4))
+    rt = large_scene(32, 2100, lights=4)
+    lightSetAvoid(rt.lights[2], [rt.shapes[11]], 1)
+    check_all_levels(rt, levels=(0, 4))
+
+
 def test_levels_are_actually_used(gpu):
     """The scenes above must really reach the screens they are meant to test."""
     def level(rt, cap=None):
@@ -155,6 +175,8 @@ def test_levels_are_actually_used(gpu):
     assert [level(scene(0, 96), cap) for cap in (0, 1, 2, 3)] == [0, 1, 2, 3]
     assert level(scenes.workload("cfg4", 64, 64)) == 3 and level(scenes.workload("cfg3", 64, 64)) == 3
     assert level(scenes.workload("cfg5", 64, 64)) == 4
+    assert level(large_scene(30, 1500, lights=5)) == 4 and level(large_scene(30, 1500, lights=5), 3) == 2
+    assert level(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7)) == 4
     assert level(scene(20, 100, lights=9)) == 2          # too many lights for the family tables
     assert level(scene(1, 40)) == 1                      # too few spheres for grouping
     assert level(scenes.default_scene()) == 1            # planes: per-sphere screen only
