@@ -28,4 +28,5 @@ print("%s: waves %d, tiles %d, wave-rounds %d (%.1f lanes busy per round), cycle
       % (name, waves, tiles, rounds, rays / max(rounds, 1), total / max(waves, 1), 100.0 * hit / total,
          100.0 * (loop - hit) / total, 100.0 * (total - loop) / total, hit / max(rounds, 1), (loop - hit) / max(rounds, 1),
          (total - loop) / tiles))
-print("   per wave-round: %.1f groups whose members were screened, %.1f exact sphere tests" % (c[7] / max(rounds, 1), c[8] / max(rounds, 1)))
+print("   per wave-round: %.1f third-level entries opened, %.1f groups whose members were screened, %.1f exact sphere tests"
+      % (c[9] / max(rounds, 1), c[7] / max(rounds, 1), c[8] / max(rounds, 1)))

@@ -482,22 +482,90 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                 a0 = nb[4 * F]; a1 = nb[5 * F]; a2 = nb[6 * F]; a3 = nb[7 * F];
                 groups4(b0, b1, b2, b3, j + 4);
             }
-        } else {  // three levels: scan the entries that stand for 8 groups each; open the groups of those that pass
+        } else {
+            // Three levels: scan the entries that stand for 8 groups each and open the groups of those that pass.
+            // Control flow below the scan is uniform over the lanes of this walk (branches on ballots, the lane's own
+            // condition travels as a predicate), so that the expensive exact test can be deferred: a lane parks its
+            // candidate sphere in `pending`, and one exact test runs for ALL lanes with a parked candidate when some
+            // lane needs the slot again (and once at the end).  With divergent secondary rays every lane meets
+            // different spheres; this way the exact test runs about as often as the busiest lane needs it rather
+            // than once per distinct sphere of the wave.
+            int pending = -1;
+            auto flush = [&]() {
+                if (pending >= 0) {
+#ifdef GRAFT_STAMPS
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
+#endif
+                    exactSphere(geom, pending, pending, sx, sy, sz, dx, dy, dz, minDist, h);
+                    pending = -1;
+                }
+            };
+            auto membersU = [&](auto *mb, int stride, int pos, bool inGroup) {
+                float f0, f1, f2, f3;
+                evaluate(mb[0], mb[stride], mb[2 * stride], mb[3 * stride], f0, f1, f2, f3);
+                const float best = __builtin_fmaxf(__builtin_fmaxf(f0, f1), __builtin_fmaxf(f2, f3));
+                if (__ballot(inGroup && !(best < limit))) {
+#pragma nounroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float fv = v == 0 ? f0 : v == 1 ? f1 : v == 2 ? f2 : f3;
+                        bool want = inGroup && !(fv < limit);
+                        if (__ballot(want)) {
+                            int shape = -1;
+                            if (want) shape = P.memberShape[(size_t)(pos + v) * F + family];
+                            want = want && shape >= 0;
+                            if (AVOID == 1) want = want && shape != avoidShape;
+                            if (AVOID == 2) want = want && !(avoidRow && shape >= 0 && avoidRow[shape]);
+                            if (__ballot(want && pending >= 0)) flush();
+                            if (want) pending = shape;
+                        }
+                    }
+                }
+            };
+            auto groupsU = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j, bool inSuper) {
+                float e0, e1, e2, e3;
+                evaluate(c0, c1, c2, c3, e0, e1, e2, e3);
+                const float best = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
+                if (__ballot(inSuper && !(best < limit))) {
+#pragma nounroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float eu = u == 0 ? e0 : u == 1 ? e1 : u == 2 ? e2 : e3;
+                        const bool inGroup = inSuper && !(eu < limit);
+                        if (__ballot(inGroup)) {
+#ifdef GRAFT_STAMPS
+                            if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
+#endif
+                            if (CONE) {
+                                const float4v *mb = (const float4v *)P.geomF + (size_t)(P.memberBase + (j + u) * 8) * F + family;
+                                membersU(mb, F, (j + u) * 8, inGroup);
+                                membersU(mb + 4 * F, F, (j + u) * 8 + 4, inGroup);
+                            } else {
+                                const float4v *mb = (const float4v *)ldsGeom + P.ballMembersLds + (j + u) * 8;
+                                membersU(mb, 1, (j + u) * 8, inGroup);
+                                membersU(mb + 4, 1, (j + u) * 8 + 4, inGroup);
+                            }
+                        }
+                    }
+                }
+            };
             const float4v *sup = (const float4v *)ldsGeom + P.superLds + family;
             auto supers4 = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j) {
                 float e0, e1, e2, e3;
                 evaluate(c0, c1, c2, c3, e0, e1, e2, e3);
                 const float best = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
-                if (!(best < limit)) {
+                if (__ballot(!(best < limit))) {
 #pragma nounroll
                     for (int u = 0; u < 4; ++u) {
                         const float eu = u == 0 ? e0 : u == 1 ? e1 : u == 2 ? e2 : e3;
-                        if (!(eu < limit)) {
+                        const bool inSuper = !(eu < limit);
+                        if (__ballot(inSuper)) {
+#ifdef GRAFT_STAMPS
+                            if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 9, 1ull);
+#endif
 #pragma nounroll
                             for (int half = 0; half < 2; ++half) {
                                 const int g0 = (j + u) * 8 + 4 * half;
                                 const float4v *gb = table + (size_t)g0 * F;
-                                groups4(gb[0], gb[F], gb[2 * F], gb[3 * F], g0);
+                                groupsU(gb[0], gb[F], gb[2 * F], gb[3 * F], g0, inSuper);
                             }
                         }
                     }
@@ -511,6 +579,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                 a0 = nb[4 * F]; a1 = nb[5 * F]; a2 = nb[6 * F]; a3 = nb[7 * F];
                 supers4(b0, b1, b2, b3, j + 4);
             }
+            flush();
         }
     };
     if (family != P.ballFamily) walk(std::true_type{});
