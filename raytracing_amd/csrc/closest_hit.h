@@ -389,8 +389,9 @@ __device__ __forceinline__ void coneBlock(const float4v c0, const float4v c1, co
 // view passes through the camera position and every shadow ray through its light: for those families the host
 // builds cone tables (packConeTable) whose test costs 4 packed instructions per two entries and culls by
 // direction alone; reflected rays use the ball table (family `ballFamily`, as closestHitGrouped).  The tables are
-// interleaved entry by entry (entry e of family f at float4 index e * families + f), so lanes of one wave may
-// follow different families at full LDS rate.  Spheres are met out of index order; see closestHitGrouped for
+// interleaved block by block (block b of family f, four entries = 64 bytes, at float4 index 4 * (b * families + f)):
+// a lane reads a block through one address with four fixed offsets, and lanes of one wave that follow different
+// families read different 64-byte slots.  Spheres are met out of index order; see closestHitGrouped for
 // why the winner does not depend on it.
 // SUPER (scenes whose member sections do not fit in LDS): only the group sections of all families, the ball
 // family's member section and the third-level sections are staged in LDS; cone members are read from the table in
@@ -404,7 +405,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                                                    double dy, double dz, int avoidShape, const unsigned char *avoidRow,
                                                    int family, float negThreshold, Hit &h) {
     const int F = P.families;
-    const float4v *table = (const float4v *)ldsGeom + family;  // this lane's column of the interleaved table
+    const float4v *table = (const float4v *)ldsGeom + 4 * family;  // this lane's blocks of the interleaved table
     const double *geom = EXACTLDS ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
     double minDist = -1;
     h.idx = -1;
@@ -423,9 +424,9 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
             if (CONE) coneBlock(c0, c1, c2, c3, dxf, dyf, dzf, e0, e1, e2, e3);
             else screenBlock(c0, c1, c2, c3, sxf, syf, szf, dxf, dyf, dzf, e0, e1, e2, e3);
         };
-        auto members4 = [&](auto *mb, int stride, int pos) {
+        auto members4 = [&](auto *mb, int pos) {
             float f0, f1, f2, f3;
-            evaluate(mb[0], mb[stride], mb[2 * stride], mb[3 * stride], f0, f1, f2, f3);
+            evaluate(mb[0], mb[1], mb[2], mb[3], f0, f1, f2, f3);
             const float best = __builtin_fmaxf(__builtin_fmaxf(f0, f1), __builtin_fmaxf(f2, f3));
             if (!(best < limit)) {
 #pragma nounroll
@@ -458,28 +459,30 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
 #endif
                         if (!SUPER) {
                             const float4v *mb = table + (size_t)(P.memberBase + (j + u) * 8) * F;
-                            members4(mb, F, (j + u) * 8);
-                            members4(mb + 4 * F, F, (j + u) * 8 + 4);
+                            members4(mb, (j + u) * 8);
+                            members4(mb + 4 * F, (j + u) * 8 + 4);
                         } else if (CONE) {
-                            const float4v *mb = (const float4v *)P.geomF + (size_t)(P.memberBase + (j + u) * 8) * F + family;
-                            members4(mb, F, (j + u) * 8);
-                            members4(mb + 4 * F, F, (j + u) * 8 + 4);
+                            const float4v *mb = (const float4v *)P.geomF + (size_t)(P.memberBase + (j + u) * 8) * F + 4 * family;
+                            members4(mb, (j + u) * 8);
+                            members4(mb + 4 * F, (j + u) * 8 + 4);
                         } else {
                             const float4v *mb = (const float4v *)ldsGeom + P.ballMembersLds + (j + u) * 8;
-                            members4(mb, 1, (j + u) * 8);
-                            members4(mb + 4, 1, (j + u) * 8 + 4);
+                            members4(mb, (j + u) * 8);
+                            members4(mb + 4, (j + u) * 8 + 4);
                         }
                     }
                 }
             }
         };
         if (!SUPER) {  // two levels: scan every group entry
-            float4v a0 = table[0], a1 = table[F], a2 = table[2 * F], a3 = table[3 * F];
+            float4v a0 = table[0], a1 = table[1], a2 = table[2], a3 = table[3];
+            const float4v *nb = table + 4 * F;  // the lane's next block: one address, four reads at fixed offsets
             for (int j = 0; j < P.groupEntries; j += 8) {
-                const float4v *nb = table + (size_t)(j + 4) * F;
-                const float4v b0 = nb[0], b1 = nb[F], b2 = nb[2 * F], b3 = nb[3 * F];
+                const float4v b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3];
                 groups4(a0, a1, a2, a3, j);
-                a0 = nb[4 * F]; a1 = nb[5 * F]; a2 = nb[6 * F]; a3 = nb[7 * F];
+                nb += 4 * F;
+                a0 = nb[0]; a1 = nb[1]; a2 = nb[2]; a3 = nb[3];
+                nb += 4 * F;
                 groups4(b0, b1, b2, b3, j + 4);
             }
         } else {
@@ -500,9 +503,9 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                     pending = -1;
                 }
             };
-            auto membersU = [&](auto *mb, int stride, int pos, bool inGroup) {
+            auto membersU = [&](auto *mb, int pos, bool inGroup) {
                 float f0, f1, f2, f3;
-                evaluate(mb[0], mb[stride], mb[2 * stride], mb[3 * stride], f0, f1, f2, f3);
+                evaluate(mb[0], mb[1], mb[2], mb[3], f0, f1, f2, f3);
                 const float best = __builtin_fmaxf(__builtin_fmaxf(f0, f1), __builtin_fmaxf(f2, f3));
                 if (__ballot(inGroup && !(best < limit))) {
 #pragma nounroll
@@ -535,19 +538,19 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                             if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
 #endif
                             if (CONE) {
-                                const float4v *mb = (const float4v *)P.geomF + (size_t)(P.memberBase + (j + u) * 8) * F + family;
-                                membersU(mb, F, (j + u) * 8, inGroup);
-                                membersU(mb + 4 * F, F, (j + u) * 8 + 4, inGroup);
+                                const float4v *mb = (const float4v *)P.geomF + (size_t)(P.memberBase + (j + u) * 8) * F + 4 * family;
+                                membersU(mb, (j + u) * 8, inGroup);
+                                membersU(mb + 4 * F, (j + u) * 8 + 4, inGroup);
                             } else {
                                 const float4v *mb = (const float4v *)ldsGeom + P.ballMembersLds + (j + u) * 8;
-                                membersU(mb, 1, (j + u) * 8, inGroup);
-                                membersU(mb + 4, 1, (j + u) * 8 + 4, inGroup);
+                                membersU(mb, (j + u) * 8, inGroup);
+                                membersU(mb + 4, (j + u) * 8 + 4, inGroup);
                             }
                         }
                     }
                 }
             };
-            const float4v *sup = (const float4v *)ldsGeom + P.superLds + family;
+            const float4v *sup = (const float4v *)ldsGeom + P.superLds + 4 * family;
             auto supers4 = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j) {
                 float e0, e1, e2, e3;
                 evaluate(c0, c1, c2, c3, e0, e1, e2, e3);
@@ -565,18 +568,20 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                             for (int half = 0; half < 2; ++half) {
                                 const int g0 = (j + u) * 8 + 4 * half;
                                 const float4v *gb = table + (size_t)g0 * F;
-                                groupsU(gb[0], gb[F], gb[2 * F], gb[3 * F], g0, inSuper);
+                                groupsU(gb[0], gb[1], gb[2], gb[3], g0, inSuper);
                             }
                         }
                     }
                 }
             };
-            float4v a0 = sup[0], a1 = sup[F], a2 = sup[2 * F], a3 = sup[3 * F];
+            float4v a0 = sup[0], a1 = sup[1], a2 = sup[2], a3 = sup[3];
+            const float4v *nb = sup + 4 * F;
             for (int j = 0; j < P.superEntries; j += 8) {
-                const float4v *nb = sup + (size_t)(j + 4) * F;
-                const float4v b0 = nb[0], b1 = nb[F], b2 = nb[2 * F], b3 = nb[3 * F];
+                const float4v b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3];
                 supers4(a0, a1, a2, a3, j);
-                a0 = nb[4 * F]; a1 = nb[5 * F]; a2 = nb[6 * F]; a3 = nb[7 * F];
+                nb += 4 * F;
+                a0 = nb[0]; a1 = nb[1]; a2 = nb[2]; a3 = nb[3];
+                nb += 4 * F;
                 supers4(b0, b1, b2, b3, j + 4);
             }
             flush();

@@ -311,9 +311,10 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
     }
 }
 
-// Interleave the tables of several ray families entry by entry: entry e of family f lands at float4 index
-// e * families + f, and the shape index of member entry i at i * families + f.  Lanes of one wave that trace rays of
-// different families then read neighbouring 16-byte slots, which lie in different LDS banks.
+// Interleave the tables of several ray families block by block (a block = 4 packed entries = 64 bytes): block b of
+// family f lands at float4 index 4 * (b * families + f), and the shape index of member entry i at i * families + f.
+// A lane then reads a block with one address and four fixed offsets, and lanes of one wave that trace rays of
+// different families read different 64-byte slots.
 inline void interleaveFamilies(const std::vector<TwoLevelTable> &fam, std::vector<float> &entries,
                                std::vector<int> &memberShape) {
     const size_t F = fam.size(), total = fam[0].entries.size() / 4, members = fam[0].memberShape.size();
@@ -321,18 +322,18 @@ inline void interleaveFamilies(const std::vector<TwoLevelTable> &fam, std::vecto
     memberShape.assign(members * F, -1);
     for (size_t f = 0; f < F; ++f) {
         for (size_t e = 0; e < total; ++e)
-            for (int c = 0; c < 4; ++c) entries[4 * (e * F + f) + c] = fam[f].entries[4 * e + c];
+            for (int c = 0; c < 4; ++c) entries[4 * (((e / 4) * F + f) * 4 + e % 4) + c] = fam[f].entries[4 * e + c];
         for (size_t i = 0; i < members; ++i) memberShape[i * F + f] = fam[f].memberShape[i];
     }
 }
 
-// The same interleaving for the third-level sections: entry e of family f at float4 index e * families + f.
+// The same interleaving for the third-level sections.
 inline void interleaveSupers(const std::vector<TwoLevelTable> &fam, std::vector<float> &entries) {
     const size_t F = fam.size(), total = fam[0].supers.size() / 4;
     entries.assign(4 * total * F, 0.0f);
     for (size_t f = 0; f < F; ++f)
         for (size_t e = 0; e < total; ++e)
-            for (int c = 0; c < 4; ++c) entries[4 * (e * F + f) + c] = fam[f].supers[4 * e + c];
+            for (int c = 0; c < 4; ++c) entries[4 * (((e / 4) * F + f) * 4 + e % 4) + c] = fam[f].supers[4 * e + c];
 }
 
 }  // namespace graft
