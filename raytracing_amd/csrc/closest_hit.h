@@ -352,9 +352,9 @@ __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double s
 #ifdef GRAFT_STAMPS
                     if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
 #endif
-                    const float4v *mb = members + (size_t)(j + u) * 8;
-                    members4(mb, (j + u) * 8);
-                    members4(mb + 4, (j + u) * 8 + 4);
+                    const int m0 = (j + u) * P.groupSize;
+#pragma nounroll
+                    for (int m = 0; m < P.groupSize; m += 4) members4(members + m0 + m, m0 + m);
                 }
             }
         }
@@ -458,17 +458,10 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                         if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
 #endif
                         if (!SUPER) {
-                            const float4v *mb = table + (size_t)(P.memberBase + (j + u) * 8) * F;
-                            members4(mb, (j + u) * 8);
-                            members4(mb + 4 * F, (j + u) * 8 + 4);
-                        } else if (CONE) {
-                            const float4v *mb = (const float4v *)P.geomF + (size_t)(P.memberBase + (j + u) * 8) * F + 4 * family;
-                            members4(mb, (j + u) * 8);
-                            members4(mb + 4 * F, (j + u) * 8 + 4);
-                        } else {
-                            const float4v *mb = (const float4v *)ldsGeom + P.ballMembersLds + (j + u) * 8;
-                            members4(mb, (j + u) * 8);
-                            members4(mb + 4, (j + u) * 8 + 4);
+                            const int m0 = (j + u) * P.groupSize;
+                            const float4v *mb = table + (size_t)(P.memberBase + m0) * F;
+#pragma nounroll
+                            for (int m = 0; m < P.groupSize; m += 4) members4(mb + m * F, m0 + m);
                         }
                     }
                 }
@@ -538,13 +531,15 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                             if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
 #endif
                             if (CONE) {
-                                const float4v *mb = (const float4v *)P.geomF + (size_t)(P.memberBase + (j + u) * 8) * F + 4 * family;
-                                membersU(mb, (j + u) * 8, inGroup);
-                                membersU(mb + 4 * F, (j + u) * 8 + 4, inGroup);
+                                const int m0 = (j + u) * P.groupSize;
+                                const float4v *mb = (const float4v *)P.geomF + (size_t)(P.memberBase + m0) * F + 4 * family;
+#pragma nounroll
+                                for (int m = 0; m < P.groupSize; m += 4) membersU(mb + m * F, m0 + m, inGroup);
                             } else {
-                                const float4v *mb = (const float4v *)ldsGeom + P.ballMembersLds + (j + u) * 8;
-                                membersU(mb, (j + u) * 8, inGroup);
-                                membersU(mb + 4, (j + u) * 8 + 4, inGroup);
+                                const int m0 = (j + u) * P.groupSize;
+                                const float4v *mb = (const float4v *)ldsGeom + P.ballMembersLds + m0;
+#pragma nounroll
+                                for (int m = 0; m < P.groupSize; m += 4) membersU(mb + m, m0 + m, inGroup);
                             }
                         }
                     }

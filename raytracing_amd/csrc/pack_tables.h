@@ -76,7 +76,7 @@ void putEntry(float *blk, int i, float cx, float cy, float cz, float rho) {
 #endif
 }
 
-constexpr int kGroup = 8;          // spheres per group of the two-level screen
+constexpr int kGroup = 8;          // default spheres per group of the two-level screens (a multiple of 4)
 constexpr int kSuper = 8;          // groups per entry of the third level
 constexpr double kGroupMargin = 0.1;
 constexpr double kGroupScale = 1e5;  // coordinates must stay below this for the margin to cover the rounding terms
@@ -85,7 +85,7 @@ constexpr double kGroupScale = 1e5;  // coordinates must stay below this for the
 // every aligned run of kGroup * kSuper points a subtree: split the longest axis of the bounding box at the median
 // (left part a multiple of kGroup * kSuper while more than that many points remain, of kGroup below) until at most
 // kGroup points remain; ties by index, so the result is deterministic.
-inline std::vector<int> kdLeafOrder(const std::vector<double> &pts, int n) {
+inline std::vector<int> kdLeafOrder(const std::vector<double> &pts, int n, int kGroup) {
     std::vector<int> idx(n);
     for (int k = 0; k < n; ++k) idx[k] = k;
     std::vector<std::pair<int, int>> todo{{0, n}};
@@ -116,16 +116,17 @@ inline std::vector<int> kdLeafOrder(const std::vector<double> &pts, int n) {
 }
 
 // One two-level table: [group entries, padded to a multiple of 8][8 entries of padding: the loop fetches two blocks
-// ahead][8 member entries (2 blocks) per group][8 entries of padding], 4 floats per entry, packed in blocks of 4
-// (putEntry); memberShape[g * 8 + m] is the shape index of a member entry, -1 for padding.
+// ahead][kGroup member entries (kGroup / 4 blocks) per group][8 entries of padding], 4 floats per entry, packed in
+// blocks of 4 (putEntry); memberShape[g * kGroup + m] is the shape index of a member entry, -1 for padding.
 struct TwoLevelTable {
     std::vector<float> entries;
     std::vector<int> memberShape;
     // third level: one entry per kSuper consecutive groups, padded to a multiple of 8 plus 8 entries (the scan fetches
     // two blocks ahead), same packing
     std::vector<float> supers;
-    int groupEntries = 0, memberBase = 0, superEntries = 0;
-    void shape(int n, float neverPass) {
+    int groupEntries = 0, memberBase = 0, superEntries = 0, kGroup = graft::kGroup;
+    void shape(int n, float neverPass, int groupSize) {
+        kGroup = groupSize;
         const int nGroups = (n + kGroup - 1) / kGroup;
         groupEntries = (nGroups + 7) / 8 * 8;
         superEntries = (groupEntries / kSuper + 7) / 8 * 8;
@@ -148,7 +149,7 @@ struct TwoLevelTable {
 
 // Two-level BALL table for a scene of spheres only (see closestHitGrouped): groups are k-d leaves of the centres,
 // each with a bounding ball.  Returns false when the scene does not qualify.
-inline bool packBallTable(const std::vector<double> &sph, TwoLevelTable &T) {
+inline bool packBallTable(const std::vector<double> &sph, int kGroup, TwoLevelTable &T) {
     const int n = (int)(sph.size() / 4);
     if (n < 64) return false;
     std::vector<double> pts(3 * (size_t)n);
@@ -157,8 +158,8 @@ inline bool packBallTable(const std::vector<double> &sph, TwoLevelTable &T) {
         if (!(fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + sqrt(c[3]) < kGroupScale)) return false;  // also rejects NaN
         for (int a = 0; a < 3; ++a) pts[3 * (size_t)k + a] = c[a];
     }
-    const std::vector<int> order = kdLeafOrder(pts, n);
-    T.shape(n, -INFINITY);  // rho = -inf never passes
+    const std::vector<int> order = kdLeafOrder(pts, n, kGroup);
+    T.shape(n, -INFINITY, kGroup);  // rho = -inf never passes
     // bounding ball of the spheres order[first..last): start at the centroid and walk towards the farthest sphere
     // with shrinking steps (Badoiu-Clarkson); any centre is valid, the radius is what makes the ball enclose them
     auto enclose = [&](int first, int last, double g[3], float &rho) {
@@ -230,7 +231,8 @@ inline float floatBelow(double x) {
 //     of the discriminant (< 3.3e-15 (|s|_1 + |c|_1)^2), the direction's deviation from unit length times b^2, and
 //     the distance (a few ulps of the coordinates) by which a computed ray misses the apex.
 // kappa2 = -1 always passes (apex inside or near the sphere, or a cone wider than 80 degrees); +inf never passes.
-inline void packConeTable(const std::vector<double> &sph, const double apex[3], double scale, TwoLevelTable &T) {
+inline void packConeTable(const std::vector<double> &sph, const double apex[3], double scale, int kGroup,
+                          TwoLevelTable &T) {
     const int n = (int)(sph.size() / 4);
     const double u = 5.9604644775390625e-08;
     const double eBound = 1e-13 * (4 * scale) * (4 * scale);
@@ -261,8 +263,8 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
         const double c = cos(ang + margin);
         return floatBelow(c * c - 16 * u);
     };
-    const std::vector<int> order = kdLeafOrder(dir, n);
-    T.shape(n, -INFINITY);  // the table stores -kappa2: -inf never passes
+    const std::vector<int> order = kdLeafOrder(dir, n, kGroup);
+    T.shape(n, -INFINITY, kGroup);  // the table stores -kappa2: -inf never passes
     // enclosing cone of the spheres order[first..last): axis a, and -kappa2 of its half-angle
     auto enclose = [&](int first, int last, double a[3]) -> float {
         a[0] = a[1] = a[2] = 0;

@@ -57,6 +57,7 @@ struct TraceParams {
     int filterFloats;          // floats of the single-precision screen table staged in LDS, 0 = no screen
     int groupEntries;          // grouped screen: entries of the group table (multiple of 8), 0 = not grouped
     int memberBase;            // grouped screen: first entry (float4 index) of the member table inside the screen table
+    int groupSize;             // grouped screen: member entries per group (a multiple of 4)
     int exactLdsOffset;        // bytes from the start of LDS to the staged exact doubles (EXACTLDS kernels)
     // per-family screen (SCREEN == 3): `families` interleaved two-level tables; cone families first, ball table last
     int families, ballFamily, cameraFamily, lightFamilyBase;  // cameraFamily < 0: primary rays use the ball table

@@ -156,6 +156,23 @@ def test_large_scenes_three_level_walk(gpu):
     check_all_levels(rt, levels=(0, 4))
 
 
+def test_groups_of_sixteen_and_other_sizes(gpu):
+    """Scenes of 512+ spheres whose tables fit in LDS use 16 spheres per group; GRAFT_GROUP forces other sizes."""
+    rt = large_scene(33, 600, lights=3, refl=0.4, depth=3)
+    check_all_levels(rt, levels=(0, 2, 3))
+    old = os.environ.get("GRAFT_GROUP")
+    try:
+        for size in ("4", "12", "32"):
+            os.environ["GRAFT_GROUP"] = size
+            check_all_levels(rt, levels=(2, 3))
+            check_all_levels(large_scene(30, 1500, lights=5, refl=0.5, depth=3), levels=(4,))
+    finally:
+        if old is None:
+            os.environ.pop("GRAFT_GROUP", None)
+        else:
+            os.environ["GRAFT_GROUP"] = old
+
+
 def test_levels_are_actually_used(gpu):
     """The scenes above must really reach the screens they are meant to test."""
     def level(rt, cap=None):
