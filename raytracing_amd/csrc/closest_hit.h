@@ -276,6 +276,7 @@ __device__ __forceinline__ void closestHitScreened(const TraceParams &P, double 
 
 __device__ __forceinline__ int lane64() { return (int)(threadIdx.x & 63); }
 
+
 // screening values of the four spheres of one table block
 __device__ __forceinline__ void screenBlock(const float4v c0, const float4v c1, const float4v c2, const float4v c3,
                                             float sxf, float syf, float szf, float dxf, float dyf, float dzf,
@@ -649,13 +650,26 @@ __device__ __forceinline__ int refractionRay(double refrIndex, const double loc[
 }
 
 // ray through world offsets (xo, yo) of the screen plane: mainTracing.c:405-417 / :425-437
-__device__ __forceinline__ void primaryRay(const TraceParams &P, double xo, double yo, double o[3], double d[3]) {
+__device__ __forceinline__ ConstDoubles cameraView(const TraceParams &P) {
+    return (ConstDoubles)(unsigned long long)P.camera;
+}
+
+// the screen point of world offsets (xo, yo): two getNewPoint steps, mainTracing.c:407-408 / :426-427
+__device__ __forceinline__ void screenPoint(ConstDoubles C, double xo, double yo, double o[3]) {
+    const double centre[3] = {C[CAM_SCREEN], C[CAM_SCREEN + 1], C[CAM_SCREEN + 2]};
+    const double lr[3] = {C[CAM_LR], C[CAM_LR + 1], C[CAM_LR + 2]};
+    const double ud[3] = {C[CAM_UD], C[CAM_UD + 1], C[CAM_UD + 2]};
     double col[3];
-    newPoint(P.screenCenter, P.lrVec, P.lrDen, xo, col);
-    newPoint(col, P.udVec, P.udDen, yo, o);
+    newPoint(centre, lr, C[CAM_LRDEN], xo, col);
+    newPoint(col, ud, C[CAM_UDDEN], yo, o);
+}
+
+__device__ __forceinline__ void primaryRay(const TraceParams &P, double xo, double yo, double o[3], double d[3]) {
+    const ConstDoubles C = cameraView(P);
+    screenPoint(C, xo, yo, o);
     d[0] = d[1] = d[2] = 0;
-    if (P.projectionType == GRAFT_ORTHOGRAPHIC) unit3(-P.viewDir[0], -P.viewDir[1], -P.viewDir[2], d[0], d[1], d[2]);
-    else unit3(o[0] - P.camPos[0], o[1] - P.camPos[1], o[2] - P.camPos[2], d[0], d[1], d[2]);
+    if (P.projectionType == GRAFT_ORTHOGRAPHIC) unit3(-C[CAM_VIEW], -C[CAM_VIEW + 1], -C[CAM_VIEW + 2], d[0], d[1], d[2]);
+    else unit3(o[0] - C[CAM_POS], o[1] - C[CAM_POS + 1], o[2] - C[CAM_POS + 2], d[0], d[1], d[2]);
 }
 
 __device__ __forceinline__ unsigned quant8(double v) {

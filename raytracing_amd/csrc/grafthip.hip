@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         const int iy = P.row0 + by;
         const bool inside = ix < P.nCols && by < P.bandRows;
 
-        double acc[3] = {P.background[0], P.background[1], P.background[2]};  // mainTracing.c:395
+        const ConstDoubles cam = cameraView(P);
+        double acc[3] = {cam[CAM_BACKGROUND], cam[CAM_BACKGROUND + 1], cam[CAM_BACKGROUND + 2]};  // mainTracing.c:395
         int firstIdx = -1;
         if (inside) {
             const double colI = P.colOff[ix], rowJ = P.rowOff[iy];
@@ -111,8 +112,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 double xo = colI, yo = rowJ;
                 if (P.aliasing) {  // mainTracing.c:401-406: k outer, l inner
                     const int k = s / P.numPasses, l = s - k * P.numPasses;
-                    xo = colI + P.subStepX * (double)(k + 1);
-                    yo = rowJ + P.subStepY * (double)(l + 1);
+                    xo = colI + cam[CAM_SUBX] * (double)(k + 1);
+                    yo = rowJ + cam[CAM_SUBY] * (double)(l + 1);
                 }
                 primaryRay(P, xo, yo, o, d);
                 depth = 0;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 if (mode == M_RADIANCE) {
                     if (depth == 0 && sample == 0 && !P.aliasing) firstIdx = h.idx;
                     if (h.idx < 0) {  // mainTracing.c:314-317
-                        v[0] = P.background[0]; v[1] = P.background[1]; v[2] = P.background[2];
+                        v[0] = cam[CAM_BACKGROUND]; v[1] = cam[CAM_BACKGROUND + 1]; v[2] = cam[CAM_BACKGROUND + 2];
                         unwind = true;
                     } else {
                         hitIdx = h.idx;
@@ -661,13 +662,15 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     if (!job) return fail(GRAFT_ERR_HIP, "graftJobCreate: out of host memory");
     TraceParams &P = job->P;
     memset(&P, 0, sizeof P);
+    DevCamera cam;
+    memset(&cam, 0, sizeof cam);
     for (int c = 0; c < 3; ++c) {
-        P.screenCenter[c] = view->screenCenter[c]; P.camPos[c] = view->camPos[c]; P.viewDir[c] = view->viewDir[c];
-        P.lrVec[c] = view->lrVec[c]; P.udVec[c] = view->udVec[c]; P.background[c] = scene->backgroundColor[c];
+        cam.screenCenter[c] = view->screenCenter[c]; cam.camPos[c] = view->camPos[c]; cam.viewDir[c] = view->viewDir[c];
+        cam.lrVec[c] = view->lrVec[c]; cam.udVec[c] = view->udVec[c]; cam.background[c] = scene->backgroundColor[c];
     }
-    P.lrDen = P.lrVec[0] * P.lrVec[0] + P.lrVec[1] * P.lrVec[1] + P.lrVec[2] * P.lrVec[2];
-    P.udDen = P.udVec[0] * P.udVec[0] + P.udVec[1] * P.udVec[1] + P.udVec[2] * P.udVec[2];
-    P.subStepX = view->subStepX; P.subStepY = view->subStepY;
+    cam.lrDen = cam.lrVec[0] * cam.lrVec[0] + cam.lrVec[1] * cam.lrVec[1] + cam.lrVec[2] * cam.lrVec[2];
+    cam.udDen = cam.udVec[0] * cam.udVec[0] + cam.udVec[1] * cam.udVec[1] + cam.udVec[2] * cam.udVec[2];
+    cam.subStepX = view->subStepX; cam.subStepY = view->subStepY;
     P.projectionType = view->projectionType; P.aliasing = view->aliasing ? 1 : 0;
     P.numPasses = view->numPasses; P.maxDepth = scene->maxDepth;
     P.numShapes = nS; P.numLights = nL; P.numRuns = (int)runs.size(); P.numSpheres = (int)(sph.size() / 4);
@@ -764,7 +767,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     if (screen == 1) packScreenTable(sph, runs, tableF);
     P.filterFloats = (int)tableF.size();
 
-    // one arena: geometry | float table | runs | materials | lights | mask | colOff | rowOff | cursor+counters
+    // one arena: geometry | float table | runs | materials | lights | mask | colOff | rowOff | camera | cursor+counters
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t oGeom = 0, oGeomF = align(oGeom + sizeof(double) * (P.geomDoubles + 1));
     size_t oMember = align(oGeomF + sizeof(float) * (tableF.size() + 1));
@@ -774,7 +777,8 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     size_t oMask = align(oLights + sizeof(DevLight) * (nL + 1));
     size_t oCol = align(oMask + mask.size() + 1);
     size_t oRow = align(oCol + sizeof(double) * view->nCols);
-    size_t oCursor = align(oRow + sizeof(double) * view->nRows);
+    size_t oCam = align(oRow + sizeof(double) * view->nRows);
+    size_t oCursor = align(oCam + sizeof(DevCamera));
     size_t total = oCursor + 256;
     std::vector<unsigned char> host(total, 0);
     if (!sph.empty()) memcpy(&host[oGeom], sph.data(), sizeof(double) * sph.size());
@@ -787,6 +791,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     if (!mask.empty()) memcpy(&host[oMask], mask.data(), mask.size());
     memcpy(&host[oCol], view->colOffsets, sizeof(double) * view->nCols);
     memcpy(&host[oRow], view->rowOffsets, sizeof(double) * view->nRows);
+    memcpy(&host[oCam], &cam, sizeof cam);
 
     hipError_t e = hipMalloc(&job->arena, total);
     if (e != hipSuccess) {
@@ -809,6 +814,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     P.avoidMask = (const unsigned char *)(base + oMask);
     P.colOff = (const double *)(base + oCol);
     P.rowOff = (const double *)(base + oRow);
+    P.camera = (const DevCamera *)(base + oCam);
     P.tileCursor = (int *)(base + oCursor);
 
     job->avoidMode = avoidMode;

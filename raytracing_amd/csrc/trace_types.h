@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "grafthip.h"
 
 namespace graft {
@@ -40,12 +42,28 @@ struct DevLight {  // 64 bytes per light
     int pad[2];
 };
 
-struct TraceParams {
-    // camera (mainTracing.c:54-62 after camInitialize)
+// Camera and background: needed once per sample, so they live in device memory and are fetched (scalar loads) where
+// they are used; as kernel arguments they would occupy 44 scalar registers for the whole kernel and push the
+// compiler into spilling scalars through vector lanes.
+struct DevCamera {
+    // mainTracing.c:54-62 after camInitialize
     double screenCenter[3], camPos[3], viewDir[3], lrVec[3], udVec[3];
     double lrDen, udDen;  // dir.dir of lrVec / udVec as getNewPoint forms it (mainTracing.c:107)
     double background[3];
     double subStepX, subStepY;
+};
+
+// The same block seen as doubles in the constant address space: loads through this view are scalar loads whatever
+// else the kernel stores to global memory (the block is written before the launch and never by a kernel).
+typedef const double __attribute__((address_space(4))) *ConstDoubles;
+enum { CAM_SCREEN = 0, CAM_POS = 3, CAM_VIEW = 6, CAM_LR = 9, CAM_UD = 12, CAM_LRDEN = 15, CAM_UDDEN = 16, CAM_BACKGROUND = 17,
+       CAM_SUBX = 20, CAM_SUBY = 21 };
+static_assert(offsetof(DevCamera, camPos) == 8 * CAM_POS && offsetof(DevCamera, udVec) == 8 * CAM_UD &&
+              offsetof(DevCamera, lrDen) == 8 * CAM_LRDEN && offsetof(DevCamera, background) == 8 * CAM_BACKGROUND &&
+              offsetof(DevCamera, subStepY) == 8 * CAM_SUBY, "DevCamera layout");
+
+struct TraceParams {
+    const DevCamera *camera;
     int projectionType, aliasing, numPasses, maxDepth;
     int numShapes, numLights, numRuns, numSpheres;
     int nCols, nRows;          // whole frame
