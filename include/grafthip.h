@@ -117,7 +117,8 @@ GRAFT_API int graftDeviceCount(void);
  * the first launchRays. */
 GRAFT_API int graftInit(int device);
 
-/* Release everything graftInit and live jobs hold.  Stands where objectDestroy stands, mainTracing.c:646-648. */
+/* Release what graftInit and graftRenderRows hold (stream, reusable device buffers).  Destroy jobs first: a job
+ * still alive keeps its device memory.  Stands where objectDestroy stands, mainTracing.c:646-648. */
 GRAFT_API void graftShutdown(void);
 
 /* Text of the last error; never NULL. */
@@ -165,7 +166,8 @@ GRAFT_API int graftSynchronize(void);
 
 /* One-shot convenience for host callers: create a job, trace rows [row0,row0+nRows) and copy the result to
  * HOST buffers (frame in `format`; hitIndex and counters optional).  This is what a launchRays() drop-in
- * calls once per frame. */
+ * calls once per frame.  The device-side frame buffers are kept and reused by later calls (grow-only, sized for the
+ * largest band rendered so far) until graftShutdown. */
 GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
                               void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost);
 

@@ -41,7 +41,9 @@ namespace {
 // rare exact tests read them from global memory.
 // TRANSP: some shape is transparent: every shaded hit may spawn a refraction ray besides the mirror ray, so the
 // per-lane stack holds a tree walk (wider entries) instead of a chain.
-template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP>
+// MANYCURSORS: tickets come from kCursors counters instead of one (launches of cheap tiles, see below).  A
+// separate instantiation because the expensive-tile kernels lose 1-3 % to any change of this code (measured).
+template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
     if (LDSGEOM) {
         if (SCREEN == 4) {
@@ -70,20 +72,43 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     const unsigned long long stampBegin = clock64();
 #endif
 
-    // Tiles are handed out by a shared cursor, `tilesPerTicket` consecutive tiles per draw (one address takes
-    // about 10^8 atomics per second, which cheap tiles -- one sample per pixel -- would exceed).  A wave's first
-    // ticket is its own number (the host starts the cursor at the number of waves); the next ticket is drawn
-    // when a ticket's first tile starts and only read after its last tile, so the atomic's round trip overlaps
-    // the work.
-    int nextTicket = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    // Tiles are handed out in tickets of `tilesPerTicket` consecutive tiles drawn from shared counters.  One address
+    // takes about 10^8 atomics per second, which cheap tiles -- one sample per pixel -- exceed even at four tiles
+    // per ticket; counters in different cache lines add up.
+    // One counter (expensive tiles): a wave's first ticket is its own number (the host starts the counter at the
+    // number of waves); the next ticket is drawn when a ticket's first tile starts and only read after its last
+    // tile, so the atomic's round trip overlaps the work.
+    // kCursors counters (cheap tiles): counter c hands out tickets c, c + kCursors, ...; a wave starts at counter
+    // (wave number mod kCursors) and moves on to the next counter when one is used up, until all are.  The next
+    // ticket is drawn ahead only when there are plenty per wave (P.prefetchTickets): a wave holding a spare ticket
+    // would otherwise starve the others.
+    int nextTicket = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));  // one counter: lane 0's draw
+    int cursor = MANYCURSORS ? nextTicket % kCursors : 0;
+    int usedUp = 0;  // counters found empty so far (wave-uniform)
+    if (MANYCURSORS && P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
     int tile = 0, tileEnd = 0;
     for (;;) {
         if (tile >= tileEnd) {
-            const int ticket = __builtin_amdgcn_readfirstlane(nextTicket);
-            tile = ticket * P.tilesPerTicket;
-            if (tile >= P.numTiles) break;  // every wave reaches this: the cursor only grows
-            tileEnd = min(tile + P.tilesPerTicket, P.numTiles);
-            if (lane == 0) nextTicket = atomicAdd(P.tileCursor, 1);
+            if (MANYCURSORS) {
+                const int numTickets = (P.numTiles + P.tilesPerTicket - 1) / P.tilesPerTicket;
+                if (!P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
+                int ticket = __builtin_amdgcn_readfirstlane(nextTicket) * kCursors + cursor;
+                while (ticket >= numTickets && ++usedUp < kCursors) {  // this counter is used up: try the next one
+                    cursor = cursor + 1 == kCursors ? 0 : cursor + 1;
+                    if (lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
+                    ticket = __builtin_amdgcn_readfirstlane(nextTicket) * kCursors + cursor;
+                }
+                if (ticket >= numTickets) break;  // every wave gets here: the counters only grow
+                tile = ticket * P.tilesPerTicket;
+                tileEnd = min(tile + P.tilesPerTicket, P.numTiles);
+                if (P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
+            } else {
+                const int ticket = __builtin_amdgcn_readfirstlane(nextTicket);
+                tile = ticket * P.tilesPerTicket;
+                if (tile >= P.numTiles) break;  // every wave reaches this: the counter only grows
+                tileEnd = min(tile + P.tilesPerTicket, P.numTiles);
+                if (lane == 0) nextTicket = atomicAdd(P.tileCursor, 1);
+            }
         }
         const int ty = tile / P.tilesX, tx = tile - ty * P.tilesX;
         const int ix = tx * kTile + lx;
@@ -426,6 +451,29 @@ int gDevice = -1;
 int gNumCU = 0;
 hipStream_t gStream = nullptr;
 
+// Device buffers graftRenderRows reuses from call to call (an interactive host calls it once per frame with the
+// same sizes): grow-only, released by graftShutdown.  hipMalloc + hipFree cost about as much as tracing a 512x512
+// frame of the reference's start-up scene.
+struct Reusable {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+Reusable gFrameBuf, gIndexBuf, gCounterBuf;
+
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -442,25 +490,31 @@ int fail(int code, const char *fmt, ...) {
 
 typedef void (*TraceFn)(const TraceParams);
 
-template <int A>
+template <int A, bool M>
 TraceFn pickKernelA(bool lds, int screen, bool exactLds) {
-    if (!lds) return screen == 2 ? traceKernel<A, false, 2, false, false> : screen == 1 ? traceKernel<A, false, 1, false, false> : traceKernel<A, false, 0, false, false>;
-    if (screen == 0) return traceKernel<A, true, 0, false, false>;
-    if (screen == 1) return exactLds ? traceKernel<A, true, 1, true, false> : traceKernel<A, true, 1, false, false>;
-    if (screen == 2) return exactLds ? traceKernel<A, true, 2, true, false> : traceKernel<A, true, 2, false, false>;
-    if (screen == 3) return exactLds ? traceKernel<A, true, 3, true, false> : traceKernel<A, true, 3, false, false>;
-    return traceKernel<A, true, 4, false, false>;
+    if (!lds) return screen == 2 ? traceKernel<A, false, 2, false, false, M> : screen == 1 ? traceKernel<A, false, 1, false, false, M> : traceKernel<A, false, 0, false, false, M>;
+    if (screen == 0) return traceKernel<A, true, 0, false, false, M>;
+    if (screen == 1) return exactLds ? traceKernel<A, true, 1, true, false, M> : traceKernel<A, true, 1, false, false, M>;
+    if (screen == 2) return exactLds ? traceKernel<A, true, 2, true, false, M> : traceKernel<A, true, 2, false, false, M>;
+    if (screen == 3) return exactLds ? traceKernel<A, true, 3, true, false, M> : traceKernel<A, true, 3, false, false, M>;
+    return traceKernel<A, true, 4, false, false, M>;
 }
 
 // Scenes with a transparent shape run the tree-walk kernels, built only for the general avoid mode, screen
 // levels 0 and 1, and exact doubles in global memory (the jobs are normalised to that in graftJobCreate).
-TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp) {
+template <bool M>
+TraceFn pickKernelM(int avoidMode, bool lds, int screen, bool exactLds, bool transp) {
     if (transp) {
-        if (lds) return screen ? traceKernel<2, true, 1, false, true> : traceKernel<2, true, 0, false, true>;
-        return screen ? traceKernel<2, false, 1, false, true> : traceKernel<2, false, 0, false, true>;
+        if (lds) return screen ? traceKernel<2, true, 1, false, true, M> : traceKernel<2, true, 0, false, true, M>;
+        return screen ? traceKernel<2, false, 1, false, true, M> : traceKernel<2, false, 0, false, true, M>;
     }
-    return avoidMode == 0 ? pickKernelA<0>(lds, screen, exactLds)
-         : avoidMode == 1 ? pickKernelA<1>(lds, screen, exactLds) : pickKernelA<2>(lds, screen, exactLds);
+    return avoidMode == 0 ? pickKernelA<0, M>(lds, screen, exactLds)
+         : avoidMode == 1 ? pickKernelA<1, M>(lds, screen, exactLds) : pickKernelA<2, M>(lds, screen, exactLds);
+}
+
+TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool manyCursors) {
+    return manyCursors ? pickKernelM<true>(avoidMode, lds, screen, exactLds, transp)
+                       : pickKernelM<false>(avoidMode, lds, screen, exactLds, transp);
 }
 
 }  // namespace
@@ -505,8 +559,9 @@ GRAFT_API int graftInit(int device) {
         for (int f = 0; f < 5; ++f)
             for (int x = 0; x < 2; ++x)
                 for (int t = 0; t < 2; ++t)
-                    HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f, x != 0, t != 0),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+                    for (int m = 0; m < 2; ++m)
+                        HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f, x != 0, t != 0, m != 0),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
     gDevice = device;
     return GRAFT_OK;
 }
@@ -516,6 +571,9 @@ GRAFT_API void graftShutdown(void) {
         (void)hipStreamSynchronize(gStream);
         (void)hipStreamDestroy(gStream);
     }
+    gFrameBuf.release();
+    gIndexBuf.release();
+    gCounterBuf.release();
     gStream = nullptr;
     gDevice = -1;
 }
@@ -779,7 +837,7 @@ GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, Gra
     size_t oRow = align(oCol + sizeof(double) * view->nCols);
     size_t oCam = align(oRow + sizeof(double) * view->nRows);
     size_t oCursor = align(oCam + sizeof(DevCamera));
-    size_t total = oCursor + 256;
+    size_t total = oCursor + sizeof(int) * kCursors * kCursorStride + 256;
     std::vector<unsigned char> host(total, 0);
     if (!sph.empty()) memcpy(&host[oGeom], sph.data(), sizeof(double) * sph.size());
     if (!pln.empty()) memcpy(&host[oGeom + sizeof(double) * sph.size()], pln.data(), sizeof(double) * pln.size());
@@ -860,7 +918,10 @@ GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void
     if (tiles > 0x7fff0000LL) return fail(GRAFT_ERR_ARG, "graftJobTrace: %lld tiles in one launch", tiles);
     P.numTiles = (int)tiles;
     const int wavesPerBlock = job->block / 64;
-    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp);
+    // cheap tiles (few samples per pixel) are drawn several at a time and from several counters
+    const int samples = P.aliasing ? P.numPasses * P.numPasses : 1;
+    const bool manyCursors = samples < 4;
+    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, manyCursors);
     if (job->blocksPerCU == 0) {  // persistent grid: as many workgroups as the kernel's registers and LDS let a CU hold
         int perCU = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)fn, job->block, job->ldsBytes));
@@ -870,14 +931,16 @@ GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void
     long long wantBlocks = (tiles + wavesPerBlock - 1) / wavesPerBlock;
     long long maxBlocks = (long long)gNumCU * blocksPerCU;
     const int grid = (int)(wantBlocks < maxBlocks ? wantBlocks : maxBlocks);
-    // cheap tiles (few samples per pixel) are drawn several at a time, but never so many that a wave gets fewer
-    // than 8 draws (load balance at the end of the launch)
-    const int samples = P.aliasing ? P.numPasses * P.numPasses : 1;
-    long long perTicket = 16 / samples < 1 ? 1 : (16 / samples > 4 ? 4 : 16 / samples);
     const long long waves = (long long)grid * wavesPerBlock;
+    // tiles per ticket: 1 for expensive tiles, 2 for cheap ones, but never so many that a wave gets fewer than 8 draws
+    // (load balance at the end of the launch)
+    long long perTicket = manyCursors ? 2 : 1;
     if (perTicket * waves * 8 > tiles) perTicket = tiles / (waves * 8) < 1 ? 1 : tiles / (waves * 8);
+    if (getenv("GRAFT_PER_TICKET")) perTicket = atoi(getenv("GRAFT_PER_TICKET")) > 0 ? atoi(getenv("GRAFT_PER_TICKET")) : 1;
     P.tilesPerTicket = (int)perTicket;
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)P.tileCursor, grid * wavesPerBlock, 1, s));
+    P.prefetchTickets = (tiles + perTicket - 1) / perTicket >= 8 * waves ? 1 : 0;
+    if (manyCursors) HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int) * kCursors * kCursorStride, s));
+    else HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)P.tileCursor, grid * wavesPerBlock, 1, s));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(job->block), job->ldsBytes, s, P);
     HIP_TRY(hipGetLastError());
     return GRAFT_OK;
@@ -902,18 +965,24 @@ GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, in
     GraftCounters *dCnt = nullptr;
     hipError_t e = hipSuccess;
     if (frameBytes == 0) rc = fail(GRAFT_ERR_ARG, "graftRenderRows: empty band or unknown format");
-    if (rc == GRAFT_OK && (e = hipMalloc(&dFrame, frameBytes)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(frame): %s", hipGetErrorString(e));
-    if (rc == GRAFT_OK && hitIndexHost && (e = hipMalloc((void **)&dIdx, px * 4)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(index): %s", hipGetErrorString(e));
+    if (rc == GRAFT_OK) {
+        if ((e = gFrameBuf.reserve(frameBytes)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(frame, %zu): %s", frameBytes, hipGetErrorString(e));
+        dFrame = gFrameBuf.ptr;
+    }
+    if (rc == GRAFT_OK && hitIndexHost) {
+        if ((e = gIndexBuf.reserve(px * 4)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(index): %s", hipGetErrorString(e));
+        dIdx = (int32_t *)gIndexBuf.ptr;
+    }
     if (rc == GRAFT_OK && countersHost) {
-        if ((e = hipMalloc((void **)&dCnt, sizeof(GraftCounters))) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(counters): %s", hipGetErrorString(e));
-        else if ((e = hipMemsetAsync(dCnt, 0, sizeof(GraftCounters), gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+        if ((e = gCounterBuf.reserve(sizeof(GraftCounters))) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(counters): %s", hipGetErrorString(e));
+        else if ((e = hipMemsetAsync(gCounterBuf.ptr, 0, sizeof(GraftCounters), gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+        dCnt = (GraftCounters *)gCounterBuf.ptr;
     }
     if (rc == GRAFT_OK) rc = graftJobTrace(job, row0, nRows, format, dFrame, dIdx, dCnt, nullptr);
     if (rc == GRAFT_OK && (e = hipMemcpyAsync(frameHost, dFrame, frameBytes, hipMemcpyDeviceToHost, gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(frame): %s", hipGetErrorString(e));
     if (rc == GRAFT_OK && dIdx && (e = hipMemcpyAsync(hitIndexHost, dIdx, px * 4, hipMemcpyDeviceToHost, gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(index): %s", hipGetErrorString(e));
     if (rc == GRAFT_OK && dCnt && (e = hipMemcpyAsync(countersHost, dCnt, sizeof(GraftCounters), hipMemcpyDeviceToHost, gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(counters): %s", hipGetErrorString(e));
     if ((e = hipStreamSynchronize(gStream)) != hipSuccess && rc == GRAFT_OK) rc = fail(GRAFT_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
-    (void)hipFree(dFrame); (void)hipFree(dIdx); (void)hipFree(dCnt);
     graftJobDestroy(job);
     return rc;
 }
@@ -922,21 +991,25 @@ static int probe(int which, const double *a, const double *b, double *out, size_
     if (gDevice < 0) return fail(GRAFT_ERR_STATE, "probe: call graftInit first");
     if (!a || !out || (which && !b) || n == 0) return fail(GRAFT_ERR_ARG, "probe: null argument");
     double *dA = nullptr, *dB = nullptr, *dO = nullptr;
-    HIP_TRY(hipMalloc((void **)&dA, n * 8));
-    HIP_TRY(hipMalloc((void **)&dO, n * 8));
-    HIP_TRY(hipMemcpy(dA, a, n * 8, hipMemcpyHostToDevice));
-    if (which) {
-        HIP_TRY(hipMalloc((void **)&dB, n * 8));
-        HIP_TRY(hipMemcpy(dB, b, n * 8, hipMemcpyHostToDevice));
-    }
-    const unsigned grid = (unsigned)((n + 255) / 256);
-    if (which) hipLaunchKernelGGL(probeDivKernel, dim3(grid), dim3(256), 0, gStream, dA, dB, dO, n);
-    else hipLaunchKernelGGL(probeSqrtKernel, dim3(grid), dim3(256), 0, gStream, dA, dO, n);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(gStream));
-    HIP_TRY(hipMemcpy(out, dO, n * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dO);
-    return GRAFT_OK;
+    auto run = [&]() -> int {
+        HIP_TRY(hipMalloc((void **)&dA, n * 8));
+        HIP_TRY(hipMalloc((void **)&dO, n * 8));
+        HIP_TRY(hipMemcpy(dA, a, n * 8, hipMemcpyHostToDevice));
+        if (which) {
+            HIP_TRY(hipMalloc((void **)&dB, n * 8));
+            HIP_TRY(hipMemcpy(dB, b, n * 8, hipMemcpyHostToDevice));
+        }
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        if (which) hipLaunchKernelGGL(probeDivKernel, dim3(grid), dim3(256), 0, gStream, dA, dB, dO, n);
+        else hipLaunchKernelGGL(probeSqrtKernel, dim3(grid), dim3(256), 0, gStream, dA, dO, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(gStream));
+        HIP_TRY(hipMemcpy(out, dO, n * 8, hipMemcpyDeviceToHost));
+        return GRAFT_OK;
+    };
+    const int rc = run();
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dO);  // on every path
+    return rc;
 }
 
 GRAFT_API int graftProbeSqrt(const double *a, double *out, size_t n) { return probe(0, a, nullptr, out, n); }

@@ -18,6 +18,8 @@ constexpr int kSmallBlock = 256;    // scenes whose geometry fits a quarter of t
 #define GRAFT_LARGE_BLOCK 1024
 #endif
 constexpr int kLargeBlock = GRAFT_LARGE_BLOCK;   // one workgroup per CU sharing up to the whole LDS
+constexpr int kCursors = 16;        // ticket counters of the many-counter kernels ...
+constexpr int kCursorStride = 32;   // ... one per 128-byte line
 constexpr size_t kLdsSmall = 36 * 1024;
 constexpr size_t kLdsMax = 152 * 1024;
 
@@ -69,7 +71,8 @@ struct TraceParams {
     int nCols, nRows;          // whole frame
     int row0, bandRows;        // rows traced by this launch
     int tilesX, numTiles;
-    int tilesPerTicket, pad1;  // consecutive tiles a wave takes per draw from the cursor
+    int tilesPerTicket;        // consecutive tiles a wave takes per draw from a counter
+    int prefetchTickets;       // draw the next ticket one ticket ahead (plenty of tickets per wave)
     int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
     int format;
     int filterFloats;          // floats of the single-precision screen table staged in LDS, 0 = no screen
