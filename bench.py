@@ -135,11 +135,18 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-frame512", action="store_true")
-    ap.add_argument("--chunks", type=int, default=8, help="pieces per GPU in the trace/gather pipeline (N > 1)")
+    ap.add_argument("--chunks", type=int, default=None,
+                    help="pieces per GPU in the trace/gather pipeline (N > 1); default 8 * sqrt(8 / N)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.chunks is None:
+        # Every piece is a launch of its own and ends with a tail of idle lanes (about half a tile's time, 0.14 ms
+        # on the default workload); the transfer of a rank's last piece is not hidden behind any tracing.  With B
+        # bytes per rank the sum 0.14 ms * p + B / p / link rate is smallest near p = 8 at N = 8 and grows with
+        # the square root of the bytes per rank.
+        args.chunks = max(4, int(round(8.0 * (8.0 / max(world, 1)) ** 0.5)))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
