@@ -156,8 +156,10 @@ GRAFT_API int graftJobScreenLevel(const GraftJob *job);
  * of `format`, row-major in iy then ix; `hitIndex` (optional, may be NULL) nRows*nCols int32 closest-shape
  * indices (-1 = miss) of each pixel's first primary ray (the mask of rayIntersect, mainTracing.c:157, over
  * the rays of :425-437 when anti-aliasing is off); `counters` (optional) one GraftCounters in device memory,
- * ADDED to.  Asynchronous on `stream` (a hipStream_t; NULL = the library's stream).  This is the double loop
- * of mainTracing.c:392-441 for those rows. */
+ * ADDED to.  Asynchronous on `stream` (a hipStream_t; NULL = the library's stream).  Traces of one job may be
+ * queued back to back on one stream; on different streams they must not overlap in time (a job has one set of tile
+ * counters).  At most 0x7fff0000 tiles of 8x8 pixels per call.  This is the double loop of mainTracing.c:392-441
+ * for those rows. */
 GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int32_t *hitIndex,
                             GraftCounters *counters, void *stream);
 
