@@ -58,3 +58,19 @@ def test_compute_entry_points_fail_loudly_without_init():
     rc = lib.graftJobCreate(ctypes.byref(scene), ctypes.byref(view), ctypes.byref(job))
     assert rc != GRAFT_OK and not job.value
     assert b"graftInit" in lib.graftLastError()
+
+
+def test_product_neither_imports_nor_links_the_oracle():
+    """oracle/ is test infrastructure: no file of the package, the C sources or the headers may name it, and the
+    shared library may not depend on it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for top in ("raytracing_amd", "include"):
+        for folder, _, files in os.walk(os.path.join(root, top)):
+            for name in files:
+                if name.endswith((".py", ".h", ".hip", ".c", ".cpp", "Makefile")):
+                    with open(os.path.join(folder, name), errors="replace") as f:
+                        assert "oracle" not in f.read().lower(), "%s/%s names the oracle" % (folder, name)
+    needed = subprocess.run(["readelf", "-d", os.path.join(root, "raytracing_amd", "csrc", "libgrafthip.so")],
+                            capture_output=True, text=True, check=True).stdout
+    assert "NEEDED" in needed and "oracle" not in needed.lower()
