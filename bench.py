@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 import raytracing_amd  # noqa: E402
 from raytracing_amd import scenes  # noqa: E402
 from raytracing_amd.distributed import local_rows, trace_and_gather  # noqa: E402
-from raytracing_amd.tracer import GRAFT_OUT_F32_RGBA  # noqa: E402
+from raytracing_amd.tracer import GRAFT_OUT_F32_RGBA, GRAFT_OUT_F64_RGB  # noqa: E402
 
 FLOP_PER_TEST = 17            # FP64 flops of one ray-sphere test on the miss path (shapes.c:52-54)
 PEAK_FP64_VALU = 78.6         # TFLOP/s, FMA counted as 2
@@ -77,6 +77,40 @@ def cpu_baseline(rt, gpu_band, row0, n_rows, cores, budget_rows):
     return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%d of %d rows of the same frame (evenly spaced), %.1f s of CPU work" % (len(picks), rt.HEIGHT, secs),
             "sample_matches_gpu": bool(exact)}
+
+
+def cpu_reference(name):
+    """The REAL reference (oracle/_ref: its own sources compiled for a 512x512 frame) tracing the workload's scene,
+    one sample per pixel, on one host core -- the reference is single-threaded.  The frame is compared with the GPU's
+    of the same 512x512 job, whose ray count (the kernel's own counter) gives the rate.  None where the reference
+    build is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_binding as rb
+    if name not in scenes.WORKLOADS or not rb.available("librefp_512x512.so"):
+        return None
+    rt = scenes.workload(name, 512, 512)
+    rt.aliasing, rt.numPasses = 0, 1
+    R = rb.Reference((512, 512))
+    if rt.numShapes > R.max_shapes or rt.numLights > R.max_lights:
+        return None
+    R.clear_scene()
+    R.set_screen(rt.screenWidth, rt.screenHeight)
+    R.set_background(rt.backgroundColor)
+    for s in rt.shapes[:rt.numShapes]:
+        R.add_sphere(s.unif[0:3], s.unif[3], s.reflectivity, s.unif[4:7], s.ambientLight, s.refrIndex, s.transparency)
+    for l in rt.lights[:rt.numLights]:
+        R.add_light(l.color, l.loc, [])
+    R.scene_initialize(rt.target, rt.targetToScreen, rt.screenToCam)
+    R.set_flags(rt.projectionType, 0, 1, rt.maxDepth)
+    t0 = time.perf_counter()
+    frame = R.launch(fill=0.0)
+    secs = time.perf_counter() - t0
+    rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_counters=True)
+    rays = rt.last_counters[0]
+    same = bool(np.array_equal(rt.launchRays(), frame))  # launchRays replays pixSetRGB as the reference shows it
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+            "sample": "the workload's scene at 512x512, 1 sample per pixel, through the reference's own launchRays "
+                      "(%.2f s)" % secs, "frame_matches_gpu": same}
 
 
 def frame_512(dev):
@@ -255,6 +289,9 @@ def main():
                 per_row = max(tests / H, 1.0)
                 rows = int(max(1, min(H, 15.0 * 4.0e8 * args.cpu_cores / per_row)))
             out["cpu_baseline"] = cpu_baseline(rt, band, row0, n_rows, args.cpu_cores, rows)
+            ref = cpu_reference(args.workload)
+            if ref is not None:
+                out["cpu_reference"] = ref
         print(json.dumps(out), flush=True)
     job.close()
     if world > 1:
