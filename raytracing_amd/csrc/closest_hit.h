@@ -143,6 +143,76 @@ __device__ __forceinline__ void exactSphere(const double *geom, int slot, int sh
     }
 }
 
+// Closest-hit bookkeeping of the sphere-only walks (two-level and family screens), which meet spheres out of index
+// order.  The reference compares candidates by dist = |loc - s| (mainTracing.c:141-144), a square root per hit; here
+// a candidate is kept by its ray parameter t, and dist is only formed when two candidates are too close for t to
+// decide.  With loc = s + t d evaluated as the reference does and d of unit length within 1e-2,
+// |dist - t |d|| <= 10.2 u t + u |s|_1 (u = 2^-53), so "t_new + slack < t_best - slack" with
+// slack(t) = 2e-15 (t + |s|_1) implies dist_new < dist_best, and the mirror image implies the opposite; anything
+// else (including NaN and infinities, whose comparisons are false) is decided by the reference's own rule on the
+// two distances, ties going to the lower index.  `slackScale` is 2e-15, or +inf for a ray whose direction is not
+// of unit length (then every pair is decided by distance).
+struct Best {
+    double t, dist;  // dist < 0: not formed yet
+    int shape;       // -1: no candidate yet
+};
+
+__device__ __forceinline__ double hitDistance(double t, double sx, double sy, double sz, double dx, double dy, double dz) {
+    const double lx = sx + t * dx, ly = sy + t * dy, lz = sz + t * dz;
+    const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
+    return sqrt(dot3(ex, ey, ez, ex, ey, ez));
+}
+
+// sphereIntersect (shapes.c:47-73) for sphere `shape` + the closest-hit update described above.
+__device__ __forceinline__ void exactSphereLazy(const double *geom, int shape, double sx, double sy, double sz, double dx,
+                                                double dy, double dz, double slackBase, double slackScale, Best &best) {
+    const double4v c4 = *(const double4v *)(geom + 4 * (size_t)shape);
+    const double vx = sx - c4.x, vy = sy - c4.y, vz = sz - c4.z;
+    const double b = vx * dx + vy * dy + vz * dz;
+    const double vv = vx * vx + vy * vy + vz * vz;
+    const double w = vv - c4.w;
+    // Origin outside the sphere and moving away from its centre: both roots are negative.  disc = fl(b b - w) is
+    // at least two units in the last place below fl(b b), so its root is below b and t = -b + q < 0 (shapes.c:62-66).
+    if (b > 0 && w > b * b * 8.9e-16) return;
+    const double disc = b * b - w;
+    if (!(disc < 0)) {
+        const double q = sqrt(disc);
+        const double bz = b + 0.0;  // restores the +0 of the reference's dot product
+        const double tFar = -bz + q;
+        const double tNear = -bz - q;
+        const double t = tNear >= 0 ? tNear : tFar;
+        if (!(t < 0)) {
+            if (best.shape < 0) {
+                best.t = t; best.dist = -1; best.shape = shape;
+            } else {
+                const double slackNew = slackScale * (t + slackBase), slackBest = slackScale * (best.t + slackBase);
+                if (t + slackNew < best.t - slackBest) {
+                    best.t = t; best.dist = -1; best.shape = shape;
+                } else if (!(t - slackNew > best.t + slackBest)) {
+                    if (best.dist < 0) best.dist = hitDistance(best.t, sx, sy, sz, dx, dy, dz);
+                    const double dist = hitDistance(t, sx, sy, sz, dx, dy, dz);
+                    if (dist < best.dist || (dist == best.dist && shape < best.shape)) {
+                        best.t = t; best.dist = dist; best.shape = shape;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// the Hit a walk returns for its best candidate: loc = s + t d as sphereIntersect forms it (shapes.c:67-68)
+__device__ __forceinline__ void finishBest(const Best &best, double sx, double sy, double sz, double dx, double dy,
+                                           double dz, Hit &h) {
+    h.idx = best.shape;
+    h.slot = best.shape < 0 ? 0 : best.shape;
+    h.kind = 0;
+    h.x = h.y = h.z = 0;
+    if (best.shape >= 0) {
+        h.kind = GRAFT_SPHERE;
+        h.x = sx + best.t * dx; h.y = sy + best.t * dy; h.z = sz + best.t * dz;
+    }
+}
+
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 
@@ -313,11 +383,10 @@ __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double s
     const float4v *groups = LDSGEOM ? (const float4v *)ldsGeom : (const float4v *)P.geomF;
     const float4v *members = groups + P.memberBase;
     const double *geom = EXACTLDS ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
-    double minDist = -1;
-    h.idx = -1;
-    h.slot = 0;
-    h.kind = 0;
-    h.x = h.y = h.z = 0;
+    Best closest = {0, -1, -1};
+    const double slackBase = fabs(sx) + fabs(sy) + fabs(sz);
+    const double dd = dx * dx + dy * dy + dz * dz;
+    const double slackScale = dd > 0.99 && dd < 1.01 ? 2e-15 : INFINITY;
     const float sxf = (float)sx, syf = (float)sy, szf = (float)sz;
     const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
     auto members4 = [&](const float4v *mb, int pos) {
@@ -336,7 +405,7 @@ __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double s
 #ifdef GRAFT_STAMPS
                     if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
 #endif
-                    if (!skip) exactSphere(geom, shape, shape, sx, sy, sz, dx, dy, dz, minDist, h);
+                    if (!skip) exactSphereLazy(geom, shape, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
                 }
             }
         }
@@ -367,6 +436,7 @@ __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double s
         a0 = groups[j + 8]; a1 = groups[j + 9]; a2 = groups[j + 10]; a3 = groups[j + 11];
         groups4(b0, b1, b2, b3, j + 4);
     }
+    finishBest(closest, sx, sy, sz, dx, dy, dz, h);
 }
 
 // pass values of the four entries of one CONE block for a ray direction: (a . d)^2 - kappa2; the table holds
@@ -408,11 +478,10 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
     const int F = P.families;
     const float4v *table = (const float4v *)ldsGeom + 4 * family;  // this lane's blocks of the interleaved table
     const double *geom = EXACTLDS ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
-    double minDist = -1;
-    h.idx = -1;
-    h.slot = 0;
-    h.kind = 0;
-    h.x = h.y = h.z = 0;
+    Best closest = {0, -1, -1};
+    const double slackBase = fabs(sx) + fabs(sy) + fabs(sz);
+    const double dd = dx * dx + dy * dy + dz * dz;
+    const double slackScale = dd > 0.99 && dd < 1.01 ? 2e-15 : INFINITY;
     const float sxf = (float)sx, syf = (float)sy, szf = (float)sz;
     const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
     // One walk over the lane's table; instantiated twice (cone / ball entries) and selected per lane OUTSIDE the
@@ -441,7 +510,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
 #ifdef GRAFT_STAMPS
                         if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
 #endif
-                        if (!skip) exactSphere(geom, shape, shape, sx, sy, sz, dx, dy, dz, minDist, h);
+                        if (!skip) exactSphereLazy(geom, shape, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
                     }
                 }
             }
@@ -493,7 +562,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
 #ifdef GRAFT_STAMPS
                     if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
 #endif
-                    exactSphere(geom, pending, pending, sx, sy, sz, dx, dy, dz, minDist, h);
+                    exactSphereLazy(geom, pending, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
                     pending = -1;
                 }
             };
@@ -585,6 +654,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
     };
     if (family != P.ballFamily) walk(std::true_type{});
     else walk(std::false_type{});
+    finishBest(closest, sx, sy, sz, dx, dy, dz, h);
 }
 
 // fresnel() of the reference, mainTracing.c:273-294, bug for bug: the two indices live in `float`, sinN is
