@@ -102,6 +102,28 @@ def test_duplicate_and_concentric_spheres_break_ties_by_index(gpu):
     assert idx.max() < 80 and (idx >= 0).any()  # a duplicate never wins over its lower-indexed original
 
 
+def test_nearly_coincident_spheres(gpu):
+    """Hit distances that differ by a few units in the last place: the walks compare ray parameters first and must
+    fall back to the reference's comparison of distances exactly when those cannot decide."""
+    rt = scene(22, 80, refl=0.5, depth=3)
+    for k in range(40):
+        src = rt.shapes[k]
+        eps = [0.0, 1e-15, 3e-14, 1e-13, 1e-12, 1e-10, 1e-8][k % 7]
+        c = [src.unif[0] * (1 + eps), src.unif[1] * (1 - eps), src.unif[2] + eps * 100]
+        rt.sphereSetup(src.unif[3] * (1 + (eps if k % 2 else -eps)), c, 80 + k, [.9, .1, .1], 0.3, 0.1, 1.0, 0.0)
+    rt.numShapes = 120
+    check_all_levels(rt)
+    rt = large_scene(34, 1300, lights=5, refl=0.5, depth=3)
+    n = rt.numShapes
+    for k in range(30):
+        src = rt.shapes[11 * k]
+        eps = [1e-15, 1e-13, 1e-11][k % 3]
+        rt.sphereSetup(src.unif[3] * (1 + eps), [src.unif[0] + eps * 50, src.unif[1], src.unif[2] * (1 - eps)], n + k,
+                       [.2, .9, .2], 0.3, 0.1, 1.0, 0.0)
+    rt.numShapes = n + 30
+    check_all_levels(rt, levels=(0, 4))
+
+
 def test_tiny_giant_and_far_spheres(gpu):
     rt = scene(16, 90, radius=(0.01, 3.0))
     rt.sphereSetup(5000, [0, 0, 200], 90, [.5, .5, .9], 0.2, 0.1, 1.0, 0.0)      # encloses everything
