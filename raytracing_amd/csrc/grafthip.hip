@@ -72,6 +72,55 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     const unsigned long long stampBegin = clock64();
 #endif
 
+    // rayIntersectAvoid for one ray per lane (mainTracing.c:128-153): picks the walk the job was built for; returns
+    // how many shapes the ray's avoid list removes from the brute-force count
+    auto closest = [&](const double o[3], const double d[3], int mode, int li, int depth, Hit &h) -> unsigned {
+        int avoidShape = -1;
+        const unsigned char *avoidRow = nullptr;
+        unsigned avoided = 0;
+        if (AVOID != 0 && mode == M_SHADOW) {
+            const DevLight &L = P.lights[li];
+            avoided = (unsigned)L.avoidNum;
+            if (AVOID == 1) avoidShape = L.avoidFirst;
+            if (AVOID == 2 && L.avoidNum > 0) avoidRow = P.avoidMask + (size_t)li * P.numShapes;
+        }
+        if (SCREEN) {
+            const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
+            const bool tame = s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001;
+            if (tame && (SCREEN == 1 || s1 < (SCREEN >= 3 ? P.familyScale : 1e5))) {
+                const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
+                if (SCREEN >= 3) {
+                    // which fixed point the ray's line passes through decides the table it is screened with
+                    int family = P.ballFamily;
+                    if (mode == M_SHADOW) family = P.lightFamilyBase + li;
+                    else if ((mode == M_INDEX || depth == 0) && P.cameraFamily >= 0) family = P.cameraFamily;
+                    closestHitFamilies<AVOID, EXACTLDS, SCREEN == 4>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, family, negThreshold, h);
+                } else if (SCREEN == 2) closestHitGrouped<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
+                else closestHitScreened<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
+            } else {  // exact loop over the doubles in global memory
+                closestHit<AVOID, false>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
+            }
+        } else {
+            closestHit<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
+        }
+        return avoided;
+    };
+    // one finished pixel: column ix, row `by` of the band
+    auto storePixel = [&](int ix, int by, const double acc[3], int firstIdx) {
+        const size_t p = (size_t)by * P.nCols + ix;
+        if (P.format == GRAFT_OUT_F64_RGB) {
+            double *f = (double *)P.frame + 3 * p;
+            f[0] = acc[0]; f[1] = acc[1]; f[2] = acc[2];
+        } else if (P.format == GRAFT_OUT_F32_RGBA) {
+            float4 px = make_float4((float)acc[0], (float)acc[1], (float)acc[2], 1.0f);
+            ((float4 *)P.frame)[p] = px;
+        } else {
+            unsigned w = quant8(acc[0]) | (quant8(acc[1]) << 8) | (quant8(acc[2]) << 16) | 0xff000000u;
+            ((unsigned *)P.frame)[p] = w;
+        }
+        if (P.hitIndex) P.hitIndex[p] = firstIdx;
+    };
+
     // Tiles are handed out in tickets of `tilesPerTicket` consecutive tiles drawn from shared counters.  One address
     // takes about 10^8 atomics per second, which cheap tiles -- one sample per pixel -- exceed even at four tiles
     // per ticket; counters in different cache lines add up.
@@ -172,34 +221,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 const unsigned long long stamp0 = clock64();
 #endif
                 Hit h;
-                int avoidShape = -1;
-                const unsigned char *avoidRow = nullptr;
-                unsigned avoided = 0;
-                if (AVOID != 0 && mode == M_SHADOW) {
-                    const DevLight &L = P.lights[li];
-                    avoided = (unsigned)L.avoidNum;
-                    if (AVOID == 1) avoidShape = L.avoidFirst;
-                    if (AVOID == 2 && L.avoidNum > 0) avoidRow = P.avoidMask + (size_t)li * P.numShapes;
-                }
-                if (SCREEN) {
-                    const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
-                    const bool tame = s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001;
-                    if (tame && (SCREEN == 1 || s1 < (SCREEN >= 3 ? P.familyScale : 1e5))) {
-                        const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
-                        if (SCREEN >= 3) {
-                            // which fixed point the ray's line passes through decides the table it is screened with
-                            int family = P.ballFamily;
-                            if (mode == M_SHADOW) family = P.lightFamilyBase + li;
-                            else if ((mode == M_INDEX || depth == 0) && P.cameraFamily >= 0) family = P.cameraFamily;
-                            closestHitFamilies<AVOID, EXACTLDS, SCREEN == 4>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, family, negThreshold, h);
-                        } else if (SCREEN == 2) closestHitGrouped<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
-                        else closestHitScreened<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
-                    } else {  // exact loop over the doubles in global memory
-                        closestHit<AVOID, false>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
-                    }
-                } else {
-                    closestHit<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
-                }
+                const unsigned avoided = closest(o, d, mode, li, depth, h);
                 rayCount++;
                 testCount += (unsigned)P.numShapes - avoided;
 #ifdef GRAFT_STAMPS
@@ -394,18 +416,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 const double n = (double)nSamples;
                 acc[0] = acc[0] / n; acc[1] = acc[1] / n; acc[2] = acc[2] / n;
             }
-            const size_t p = (size_t)by * P.nCols + ix;
-            if (P.format == GRAFT_OUT_F64_RGB) {
-                double *f = (double *)P.frame + 3 * p;
-                f[0] = acc[0]; f[1] = acc[1]; f[2] = acc[2];
-            } else if (P.format == GRAFT_OUT_F32_RGBA) {
-                float4 px = make_float4((float)acc[0], (float)acc[1], (float)acc[2], 1.0f);
-                ((float4 *)P.frame)[p] = px;
-            } else {
-                unsigned w = quant8(acc[0]) | (quant8(acc[1]) << 8) | (quant8(acc[2]) << 16) | 0xff000000u;
-                ((unsigned *)P.frame)[p] = w;
-            }
-            if (P.hitIndex) P.hitIndex[p] = firstIdx;
+            storePixel(ix, by, acc, firstIdx);
         }
         ++tile;
     }
