@@ -143,18 +143,19 @@ def frame_512(dev):
     return out
 
 
-def recorded_traffic(workload, frame):
-    """HBM bytes per launch measured offline with rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) on this same
-    command; kept under profiles/ because counters cannot be read from inside the process."""
+def recorded_counters(workload, frame):
+    """What the hardware counters said about this same command, measured offline with rocprofv3 PMC passes and kept
+    under profiles/ because counters cannot be read from inside the process: HBM bytes per launch (FETCH_SIZE,
+    WRITE_SIZE), fraction of cycles the vector ALUs issue, vector instructions per 64 rays."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
         if rec.get("workload") == workload and rec.get("frame") == frame:
-            return rec.get("hbm_bytes_per_launch")
+            return rec
     except (OSError, ValueError):
         pass
-    return None
+    return {}
 
 
 def main():
@@ -252,6 +253,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         achieved = FLOP_PER_TEST * local_tests / (kernel_ms * 1e-3) / 1e12
+        counters_rec = recorded_counters(args.workload, [W, H])
         out = {
             "metric": "Mrays/s", "value": rays / (elapsed / args.steps) / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -264,11 +266,15 @@ def main():
             "primary_Msamples_per_s": W * H * (rt.numPasses ** 2 if rt.aliasing else 1) / (elapsed / args.steps) / 1e6,
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU, "frac_nofma": achieved / PEAK_FP64_NOFMA,
-                         "traffic": recorded_traffic(args.workload, [W, H]), "kernel": "traceKernel", "kernel_ms": kernel_ms,
+                         "traffic": counters_rec.get("hbm_bytes_per_launch"),
+                         "valu_busy": counters_rec.get("valu_busy_fraction"),
+                         "valu_instructions_per_wave_ray": counters_rec.get("valu_instructions_per_wave_ray"),
+                         "kernel": "traceKernel", "kernel_ms": kernel_ms,
                          "tests_per_launch": local_tests, "flop_per_test": FLOP_PER_TEST,
                          "note": "achieved counts the 17 flop of the reference's brute-force test for every "
                                  "(ray, shape) pair; the kernel proves most pairs to be misses with cheaper "
-                                 "single-precision screens, so achieved can exceed the FP64 peak"},
+                                 "single-precision screens, so achieved can exceed the FP64 peak; valu_busy is the "
+                                 "measured fraction of cycles the vector ALUs issue (profiles/)"},
         }
         if world > 1:  # the assembled frame against rank 0's own trace of 16 tile rows spread over all pieces
             torch.cuda.synchronize()
