@@ -947,7 +947,8 @@ GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void
     // (load balance at the end of the launch)
     long long perTicket = manyCursors ? 2 : 1;
     if (perTicket * waves * 8 > tiles) perTicket = tiles / (waves * 8) < 1 ? 1 : tiles / (waves * 8);
-    if (getenv("GRAFT_PER_TICKET")) perTicket = atoi(getenv("GRAFT_PER_TICKET")) > 0 ? atoi(getenv("GRAFT_PER_TICKET")) : 1;
+    if (getenv("GRAFT_PER_TICKET"))  // diagnostics: force the ticket size
+        perTicket = atoi(getenv("GRAFT_PER_TICKET")) > 0 ? atoi(getenv("GRAFT_PER_TICKET")) : 1;
     P.tilesPerTicket = (int)perTicket;
     P.prefetchTickets = (tiles + perTicket - 1) / perTicket >= 8 * waves ? 1 : 0;
     if (manyCursors) HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int) * kCursors * kCursorStride, s));
