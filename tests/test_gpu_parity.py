@@ -150,3 +150,16 @@ def test_errors_are_reported(gpu):
     rt.maxDepth = 4
     with pytest.raises(GraftError):
         rt.render_rows(60, 10)  # rows outside the frame
+
+
+def test_render_rows_reuses_its_buffers(gpu):
+    """graftRenderRows keeps its device-side frame buffers between calls: a large frame, a smaller one with the
+    index plane and counters, and the large one again must each come out as on a first call."""
+    big, small = build("default_aa_off"), build("small_96x64_aa_off")
+    first = big.render_rows()
+    rgb, idx = small.render_rows(0, None, want_index=True, want_counters=True)
+    want = ob.render(small, threads=8, want_index=True, want_counters=True)
+    assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64)) and np.array_equal(idx, want["index"])
+    assert small.last_counters == want["counters"][:2]
+    again = big.render_rows()
+    assert np.array_equal(first.view(np.uint64), again.view(np.uint64))
