@@ -74,9 +74,18 @@ def cpu_baseline(rt, gpu_band, row0, n_rows, cores, budget_rows):
         if gpu_band is not None:
             mine = gpu_band[r - row0, :, :3].cpu().numpy()
             exact = exact and np.array_equal(mine, o["rgb"][0].astype(np.float32))
+    # the reference's own execution model is one thread: the same port on one core, over a few of the sampled rows
+    few = picks[::max(1, len(picks) // 4)][:4]
+    rays1, secs1 = 0, 0.0
+    for r in few:
+        t0 = time.perf_counter()
+        o = ob.render(rt, r, 1, threads=1, want_counters=True)
+        secs1 += time.perf_counter() - t0
+        rays1 += o["counters"][0]
     return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%d of %d rows of the same frame (evenly spaced), %.1f s of CPU work" % (len(picks), rt.HEIGHT, secs),
-            "sample_matches_gpu": bool(exact)}
+            "sample_matches_gpu": bool(exact),
+            "single_core_value": rays1 / secs1 / 1e6, "single_core_sample": "%d of those rows, %.1f s" % (len(few), secs1)}
 
 
 def cpu_reference(name):
