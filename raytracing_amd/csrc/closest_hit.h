@@ -216,28 +216,11 @@ __device__ __forceinline__ void finishBest(const Best &best, double sx, double s
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-#ifndef GRAFT_SCREEN_PACKED
-#define GRAFT_SCREEN_PACKED 1
-#endif
-
 // Single-precision screening value of one sphere for one ray: an approximation of the discriminant
 // b*b - (v.v - r*r) of shapes.c:54 evaluated with fused multiply-adds on operands rounded to float, with the
 // sphere's share of the worst-case error already folded into rho (see packScreenTable).  A value below the
 // ray's threshold PROVES that the double-precision discriminant of the reference is negative.
-__device__ __forceinline__ float screen1(float cx, float cy, float cz, float rho, float sx, float sy, float sz,
-                                         float dx, float dy, float dz) {
-    const float vx = sx - cx, vy = sy - cy, vz = sz - cz;
-    float b = vx * dx;
-    b = __builtin_fmaf(vy, dy, b);
-    b = __builtin_fmaf(vz, dz, b);
-    float vv = vx * vx;
-    vv = __builtin_fmaf(vy, vy, vv);
-    vv = __builtin_fmaf(vz, vz, vv);
-    float t = rho - vv;
-    return __builtin_fmaf(b, b, t);
-}
-
-// the same for two spheres at once in packed single precision (v_pk_add/mul/fma_f32)
+// Evaluated for two spheres at once in packed single precision (v_pk_add/mul/fma_f32).
 __device__ __forceinline__ float2v screen2(float2v cx, float2v cy, float2v cz, float2v rho, float2v sx, float2v sy,
                                            float2v sz, float2v dx, float2v dy, float2v dz) {
     const float2v vx = sx - cx, vy = sy - cy, vz = sz - cz;
@@ -249,6 +232,18 @@ __device__ __forceinline__ float2v screen2(float2v cx, float2v cy, float2v cz, f
     vv = __builtin_elementwise_fma(vz, vz, vv);
     const float2v t = rho - vv;
     return __builtin_elementwise_fma(b, b, t);
+}
+
+// screening values of the four spheres of one table block
+__device__ __forceinline__ void screenBlock(const float4v c0, const float4v c1, const float4v c2, const float4v c3,
+                                            float sxf, float syf, float szf, float dxf, float dyf, float dzf,
+                                            float &e0, float &e1, float &e2, float &e3) {
+    // block layout: {cx0 cx1 cy0 cy1} {cz0 cz1 rho0 rho1} {cx2 cx3 cy2 cy3} {cz2 cz3 rho2 rho3}
+    const float2v S0 = {sxf, sxf}, S1 = {syf, syf}, S2 = {szf, szf};
+    const float2v D0 = {dxf, dxf}, D1 = {dyf, dyf}, D2 = {dzf, dzf};
+    const float2v ea = screen2(c0.xy, c0.zw, c1.xy, c1.zw, S0, S1, S2, D0, D1, D2);
+    const float2v eb = screen2(c2.xy, c2.zw, c3.xy, c3.zw, S0, S1, S2, D0, D1, D2);
+    e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
 }
 
 // rayIntersectAvoid with a conservative single-precision screen in front of the exact test.  Every sphere is
@@ -289,19 +284,7 @@ __device__ __forceinline__ void closestHitScreened(const TraceParams &P, double 
             // part of the table holds a multiple of 8 entries and the table ends with 8 entries of padding.
             auto block = [&](const float4v c0, const float4v c1, const float4v c2, const float4v c3, int j) {
                 float e0, e1, e2, e3;
-#if GRAFT_SCREEN_PACKED
-                // block layout: {cx0 cx1 cy0 cy1} {cz0 cz1 rho0 rho1} {cx2 cx3 cy2 cy3} {cz2 cz3 rho2 rho3}
-                const float2v S0 = {sxf, sxf}, S1 = {syf, syf}, S2 = {szf, szf};
-                const float2v D0 = {dxf, dxf}, D1 = {dyf, dyf}, D2 = {dzf, dzf};
-                const float2v ea = screen2(c0.xy, c0.zw, c1.xy, c1.zw, S0, S1, S2, D0, D1, D2);
-                const float2v eb = screen2(c2.xy, c2.zw, c3.xy, c3.zw, S0, S1, S2, D0, D1, D2);
-                e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
-#else
-                e0 = screen1(c0.x, c0.y, c0.z, c0.w, sxf, syf, szf, dxf, dyf, dzf);
-                e1 = screen1(c1.x, c1.y, c1.z, c1.w, sxf, syf, szf, dxf, dyf, dzf);
-                e2 = screen1(c2.x, c2.y, c2.z, c2.w, sxf, syf, szf, dxf, dyf, dzf);
-                e3 = screen1(c3.x, c3.y, c3.z, c3.w, sxf, syf, szf, dxf, dyf, dzf);
-#endif
+                screenBlock(c0, c1, c2, c3, sxf, syf, szf, dxf, dyf, dzf, e0, e1, e2, e3);
                 const float best = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
                 if (!(best < negThreshold)) {  // rare: some lane may hit one of the four
                     const int k = run.count - j;  // live spheres from j on (the rest of the run's part is padding)
@@ -346,24 +329,6 @@ __device__ __forceinline__ void closestHitScreened(const TraceParams &P, double 
 
 __device__ __forceinline__ int lane64() { return (int)(threadIdx.x & 63); }
 
-
-// screening values of the four spheres of one table block
-__device__ __forceinline__ void screenBlock(const float4v c0, const float4v c1, const float4v c2, const float4v c3,
-                                            float sxf, float syf, float szf, float dxf, float dyf, float dzf,
-                                            float &e0, float &e1, float &e2, float &e3) {
-#if GRAFT_SCREEN_PACKED
-    const float2v S0 = {sxf, sxf}, S1 = {syf, syf}, S2 = {szf, szf};
-    const float2v D0 = {dxf, dxf}, D1 = {dyf, dyf}, D2 = {dzf, dzf};
-    const float2v ea = screen2(c0.xy, c0.zw, c1.xy, c1.zw, S0, S1, S2, D0, D1, D2);
-    const float2v eb = screen2(c2.xy, c2.zw, c3.xy, c3.zw, S0, S1, S2, D0, D1, D2);
-    e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
-#else
-    e0 = screen1(c0.x, c0.y, c0.z, c0.w, sxf, syf, szf, dxf, dyf, dzf);
-    e1 = screen1(c1.x, c1.y, c1.z, c1.w, sxf, syf, szf, dxf, dyf, dzf);
-    e2 = screen1(c2.x, c2.y, c2.z, c2.w, sxf, syf, szf, dxf, dyf, dzf);
-    e3 = screen1(c3.x, c3.y, c3.z, c3.w, sxf, syf, szf, dxf, dyf, dzf);
-#endif
-}
 
 // Two-level screen for sphere-only scenes: the host cuts the spheres into spatially compact groups of 8 (leaves of
 // a k-d tree); each group has a bounding ball (centre g, radius R >= |c_k - g| + r_k for its members, plus a

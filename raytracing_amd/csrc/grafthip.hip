@@ -205,11 +205,20 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 mode = M_SHADOW;
             };
 
-            if (P.hitIndex && P.aliasing) {  // mask ray = the anti-aliasing-off ray of this pixel
+            // maxDepth <= 0: shootRay returns black before it looks at the scene (mainTracing.c:302-306), for every
+            // sample; with anti-aliasing the background-seeded sum (:395) takes n additions of zero
+            const bool traceNothing = P.maxDepth <= 0;
+            if (P.hitIndex && (P.aliasing || traceNothing)) {  // mask ray = the anti-aliasing-off ray of this pixel
                 primaryRay(P, colI, rowJ, o, d);
                 mode = M_INDEX;
+            } else if (traceNothing) {
+                mode = M_DONE;
             } else {
                 startSample(0);
+            }
+            if (traceNothing) {
+                if (P.aliasing) { acc[0] = acc[0] + 0.0; acc[1] = acc[1] + 0.0; acc[2] = acc[2] + 0.0; }
+                else acc[0] = acc[1] = acc[2] = 0;
             }
 
 #ifdef GRAFT_STAMPS
@@ -236,7 +245,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 double v[3] = {0, 0, 0};
                 if (mode == M_INDEX) {
                     firstIdx = h.idx;
-                    startSample(0);
+                    if (traceNothing) mode = M_DONE;
+                    else startSample(0);
                     continue;
                 }
                 if (mode == M_RADIANCE) {

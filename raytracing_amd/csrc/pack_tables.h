@@ -16,18 +16,14 @@ namespace graft {
 // (always passes) for spheres whose coordinates are not finite or are too large for float arithmetic.  Every
 // sphere run gets its own block, padded to a multiple of eight with entries that never pass (rho = -inf), and the
 // table ends with eight more such entries because the hot loop fetches two blocks of four ahead.  Block layout:
-// GRAFT_SCREEN_PACKED = 0: {cx cy cz rho} x 4;  1: {cx0 cx1 cy0 cy1}{cz0 cz1 rho0 rho1}{cx2 cx3 cy2 cy3}{cz2 cz3 rho2 rho3}.
+// {cx0 cx1 cy0 cy1}{cz0 cz1 rho0 rho1}{cx2 cx3 cy2 cy3}{cz2 cz3 rho2 rho3}.
 void packScreenTable(const std::vector<double> &sph, std::vector<DevRun> &runs, std::vector<float> &out) {
     const double u = 5.9604644775390625e-08;
     out.clear();
     auto entry = [&](float *blk, int i, float cx, float cy, float cz, float rho) {
-#if GRAFT_SCREEN_PACKED
         float *pair = blk + 8 * (i >> 1);
         const int h = i & 1;
         pair[0 + h] = cx; pair[2 + h] = cy; pair[4 + h] = cz; pair[6 + h] = rho;
-#else
-        blk[4 * i] = cx; blk[4 * i + 1] = cy; blk[4 * i + 2] = cz; blk[4 * i + 3] = rho;
-#endif
     };
     for (DevRun &run : runs) {
         if (run.kind != GRAFT_SPHERE) continue;
@@ -67,13 +63,9 @@ bool screenRho(const double c[3], double rr, float &rho) {
 }
 
 void putEntry(float *blk, int i, float cx, float cy, float cz, float rho) {
-#if GRAFT_SCREEN_PACKED
     float *pair = blk + 8 * (i >> 1);
     const int h = i & 1;
     pair[0 + h] = cx; pair[2 + h] = cy; pair[4 + h] = cz; pair[6 + h] = rho;
-#else
-    blk[4 * i] = cx; blk[4 * i + 1] = cy; blk[4 * i + 2] = cz; blk[4 * i + 3] = rho;
-#endif
 }
 
 constexpr int kGroup = 8;          // default spheres per group of the two-level screens (a multiple of 4)

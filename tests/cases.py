@@ -144,6 +144,12 @@ _add("parallel_planes_ortho", (64, 64), [("clear",), ("plane", (0, -100, 0), (0,
                                           ("camera", (0, 0, 0), 256, 1000), ("flags", O, OFF, 1, 4)])
 
 
+# -- maxDepth <= 0: shootRay returns black before it looks at the scene (mainTracing.c:302-306); the mask of
+#    rayIntersect does not depend on it --
+_add("default_depth0", (64, 64), [("default",), ("flags", P, OFF, 6, 0)])
+_add("default_depth0_aa2", (64, 64), [("default",), ("background", (.2, .3, .4)), ("flags", P, ON, 2, 0)])
+_add("mixed_0_depth_negative", (64, 64), mixed_ops(0) + [("flags", O, ON, 3, -3)])
+
 # -- transparency: refraction() and fresnel() of the reference, bugs included (mainTracing.c:232-294) --
 _add("glass_sphere4", (128, 128), [("default",), ("flags", P, OFF, 6, 4), ("material", 3, 1.0, 0.0, 1.5, 0.8)])
 _add("glass_two_depth10", (64, 64), [("default",), ("flags", P, OFF, 6, 10), ("material", 0, 0.5, 0.1, 1.33, 0.6),

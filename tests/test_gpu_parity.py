@@ -30,9 +30,9 @@ def assert_parity(rt, row0=0, n_rows=None):
     assert same, "RGB not bit-exact: max abs diff %g in %d values" % (
         np.abs(rgb - want["rgb"]).max(), np.count_nonzero(rgb != want["rgb"]))
     # ray statistics: (closest-hit queries, ray-shape evaluations); the mask probe ray adds one query per pixel
-    # when anti-aliasing is on
+    # when anti-aliasing is on, or when maxDepth <= 0 leaves no radiance ray to read the mask from
     rays, tests = rt.last_counters
-    extra = rgb.shape[0] * rgb.shape[1] if rt.aliasing else 0
+    extra = rgb.shape[0] * rgb.shape[1] if (rt.aliasing or rt.maxDepth <= 0) else 0
     assert rays == want["counters"][0] + extra
     assert tests == want["counters"][1] + extra * rt.numShapes
     return rgb, idx
@@ -79,7 +79,7 @@ def test_gpu_matches_reference_golden(gpu, name):
 
 @pytest.mark.parametrize("name", ["cfg3_512", "cfg5_128_depth4", "mixed_1", "mixed_4_aa2_depth10", "keys_07",
                                   "parallel_planes_ortho", "camera_inside_sphere", "glass_sphere4", "glass_mixed_1",
-                                  "glass_two_depth10"])
+                                  "glass_two_depth10", "default_depth0", "default_depth0_aa2", "mixed_0_depth_negative"])
 def test_gpu_matches_oracle_counters(gpu, name):
     assert_parity(build(name))
 
