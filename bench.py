@@ -10,14 +10,19 @@ is being traced.  Prints ONE JSON line on rank 0.
 
 metric  Mrays/s, ray = one closest-hit query (primary + shadow + reflection; rayIntersectAvoid of the
         reference, mainTracing.c:128), counted by the kernel itself in an untimed pass.
-roofline  the trace kernel is bound by the FP64 vector ALU: achieved = 17 flop x ray-shape tests per launch
-        / mean kernel time (HIP events on the launch stream, inside the timed region); peak 78.6 TFLOP/s
-        = 256 CU x 4 SIMD x 16 FP64 lanes x 2 flop (FMA) x 2.4 GHz.  The bit-exact instruction mix cannot
-        use FMA, so 39.3 TFLOP/s is its real ceiling (reported as frac_nofma).
+roofline  the trace kernel is bound by the vector ALU.  achieved = FP64 flop the kernel EXECUTED per launch (hardware
+        counters of the same command, kept under profiles/ because counters cannot be read in-process:
+        (ADD + MUL + 2 FMA + TRANS wave-instructions) x 64 lanes) / mean kernel time measured here (HIP events on the
+        launch stream, inside the timed region); peak 78.6 TFLOP/s = 256 CU x 4 SIMD x 16 FP64 lanes x 2 flop (FMA)
+        x 2.4 GHz.  The bit-exact instruction mix cannot fuse multiply and add, so 39.3 TFLOP/s is its ceiling
+        (frac_nofma).  `algorithmic` holds the other view: 17 flop of the reference's brute-force test for every
+        (ray, shape) pair / kernel time -- the screens prove most pairs to be misses without executing them, so that
+        rate can exceed the peak; it is a speed-up over brute force, not a utilisation.
 cpu_baseline  the CPU oracle (a port of the reference, bit-exact to it) on a bounded sample of rows of the
         SAME frame, on `cores` host threads; the sampled rows are also compared with the GPU's.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -38,6 +43,7 @@ from raytracing_amd.tracer import GRAFT_OUT_F32_RGBA, GRAFT_OUT_F64_RGB  # noqa:
 FLOP_PER_TEST = 17            # FP64 flops of one ray-sphere test on the miss path (shapes.c:52-54)
 PEAK_FP64_VALU = 78.6         # TFLOP/s, FMA counted as 2
 PEAK_FP64_NOFMA = 39.3        # TFLOP/s when every mul and add issues separately
+PEAK_FP32_VALU = 157.3        # TFLOP/s, packed FMA
 
 
 def build_workload(name, width=None, height=None):
@@ -123,14 +129,31 @@ def cpu_reference(name):
 
 
 def frame_512(dev):
-    """The metric's "512x512 frame time": the reference's start-up scene cut to one sphere + one light (1 spp) and
-    the full start-up scene (6x6 supersampling), as kernel time (HIP events) and, for the former, as one whole
-    launchRays-style call with host buffers (scene upload + trace + copy back over PCIe)."""
+    """The metric's "512x512 frame time" and what the host pays around the kernel.  Per scene (the reference's
+    start-up scene cut to one sphere + one light at 1 spp; the full start-up scene with 6x6 supersampling; the cfg3
+    scene at 1 spp): kernel time (HIP events), graftJobCreate (pack + upload) on a first call and on a second call
+    that finds the screen tables in the library's cache, and one whole launchRays-style call with host buffers
+    (graftRenderRows into a page-locked frame: pack + upload + trace + copy back over PCIe) on the first call and
+    when scene and view are unchanged since the call before."""
+    import ctypes
+    from raytracing_amd._lib import check, lib
     out = {}
     stream = torch.cuda.current_stream()
-    for key, name in (("single_sphere", "single"), ("startup_scene_aa6", "default")):
-        rt, _ = build_workload(name)
+
+    def cfg3_512():
+        rt = scenes.workload("cfg3", 512, 512)
+        return rt
+
+    for key, make in (("single_sphere", lambda: build_workload("single")[0]),
+                      ("startup_scene_aa6", lambda: build_workload("default")[0]), ("cfg3_scene_512", cfg3_512)):
+        rt = make()
+        t0 = time.perf_counter()
         job = rt.create_job()
+        out[key + "_job_create_first_ms"] = (time.perf_counter() - t0) * 1e3
+        job.close()
+        t0 = time.perf_counter()
+        job = rt.create_job()
+        out[key + "_job_create_again_ms"] = (time.perf_counter() - t0) * 1e3
         buf = torch.empty((job.nRows, job.nCols, 4), dtype=torch.float32, device=dev)
         for _ in range(3):
             job.trace(0, job.nRows, GRAFT_OUT_F32_RGBA, buf.data_ptr(), None, None, stream.cuda_stream)
@@ -143,28 +166,109 @@ def frame_512(dev):
         torch.cuda.synchronize()
         out[key + "_kernel_ms"] = a.elapsed_time(b) / reps
         job.close()
-        if name == "single":
-            rt.render_rows()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                rt.render_rows()
-            out[key + "_host_call_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        # whole host calls: the doubles pixSetRGB receives (24 bytes per pixel), into page-locked memory
+        scene, view, keep = rt.pack()
+        nbytes = view.nRows * view.nCols * 24
+        host = ctypes.c_void_p()
+        check(lib.graftHostAlloc(nbytes, ctypes.byref(host)))
+        call = lambda: check(lib.graftRenderRows(ctypes.byref(scene), ctypes.byref(view), 0, view.nRows,
+                                                 GRAFT_OUT_F64_RGB, host, None, None))
+        other = build_workload("single" if key != "single_sphere" else "default")[0]
+        other.render_rows(0, 8)  # puts another job in the library's one-entry cache
+        t0 = time.perf_counter()
+        call()
+        out[key + "_host_call_first_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        for _ in range(5):
+            call()
+        out[key + "_host_call_unchanged_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        job = rt.create_job()
+        f64 = torch.empty((view.nRows, view.nCols, 3), dtype=torch.float64, device=dev)
+        job.trace(0, view.nRows, GRAFT_OUT_F64_RGB, f64.data_ptr(), None, None, stream.cuda_stream)
+        a.record()
+        for _ in range(reps):
+            job.trace(0, view.nRows, GRAFT_OUT_F64_RGB, f64.data_ptr(), None, None, stream.cuda_stream)
+        b.record()
+        torch.cuda.synchronize()
+        out[key + "_kernel_f64_ms"] = a.elapsed_time(b) / reps
+        job.close()
+        lib.graftHostFree(host)
+        del keep
     return out
 
 
-def recorded_counters(workload, frame):
-    """What the hardware counters said about this same command, measured offline with rocprofv3 PMC passes and kept
-    under profiles/ because counters cannot be read from inside the process: HBM bytes per launch (FETCH_SIZE,
-    WRITE_SIZE), fraction of cycles the vector ALUs issue, vector instructions per 64 rays."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+KERNEL_SOURCES = ("grafthip.hip", "closest_hit.h", "trace_types.h", "pack_tables.h", "host_job.h")
+
+
+def kernel_source_hash():
+    """Fingerprint of the sources libgrafthip.so is built from: a counter record belongs to one build."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "raytracing_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_counters(workload, frame, screen_cap):
+    """What the hardware counters said about this same command (profiles/collect_pmc.sh + summarize_pmc.py):
+    profiles/pmc_<workload>[_level<cap>].json.  Returns (record, note): the record is used only when it was taken
+    on this frame size; the note says whether it belongs to the build that is running."""
+    name = "pmc_%s%s.json" % (workload, "" if screen_cap >= 4 else "_level%d" % screen_cap)
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             rec = json.load(f)
-        if rec.get("workload") == workload and rec.get("frame") == frame:
-            return rec
     except (OSError, ValueError):
-        pass
-    return {}
+        return None, "no counter record profiles/%s" % name
+    if rec.get("frame") != frame:
+        return None, "profiles/%s was taken on frame %s" % (name, rec.get("frame"))
+    same = rec.get("kernel_source_hash") == kernel_source_hash()
+    return rec, "profiles/%s, %s" % (name, "same kernel sources" if same else
+                                     "RECORDED ON AN OLDER BUILD (%s)" % rec.get("kernel_source_hash"))
+
+
+def roofline(rec, note, kernel_ms, local_tests):
+    """Executed-work roofline of the trace kernel from the recorded counters and the kernel time measured now."""
+    secs = kernel_ms * 1e-3
+    algorithmic = FLOP_PER_TEST * local_tests / secs / 1e12
+    out = {"bound": "valu_fp64", "achieved": None, "peak": PEAK_FP64_VALU, "unit": "TFLOP/s", "frac": None,
+           "frac_nofma": None, "traffic": None, "kernel": "traceKernel", "kernel_ms": kernel_ms,
+           "counters": note,
+           "algorithmic": {"tflops": algorithmic, "flop_per_test": FLOP_PER_TEST, "tests_per_launch": local_tests,
+                           "speedup_over_fp64_brute_force_ceiling": algorithmic / PEAK_FP64_VALU,
+                           "note": "17 flop of the reference's test for every (ray, shape) pair; pairs the screens "
+                                   "prove to be misses are counted although they are never executed"}}
+    if rec:
+        c = rec["counters"]
+        f64 = (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"]
+               + c["SQ_INSTS_VALU_TRANS_F64"]) * 64
+        f32 = (c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + 2 * c["SQ_INSTS_VALU_FMA_F32"]) * 64
+        fp_instr = sum(c[k] for k in c if k.startswith("SQ_INSTS_VALU_") and k.endswith(("_F64", "_F32")))
+        out.update({
+            "achieved": f64 / secs / 1e12, "frac": f64 / secs / 1e12 / PEAK_FP64_VALU,
+            "frac_nofma": f64 / secs / 1e12 / PEAK_FP64_NOFMA,
+            "executed_fp64_flop_per_launch": f64,
+            "executed_fp32_tflops": {"unpacked": f32 / secs / 1e12, "if_all_packed": 2 * f32 / secs / 1e12,
+                                     "peak": PEAK_FP32_VALU},
+            "fp_share_of_valu_instructions": fp_instr / c["SQ_INSTS_VALU"],
+            "valu_busy": rec["derived"].get("valu_busy_fraction_per_simd"),
+            "lane_utilisation": rec["derived"].get("lane_utilisation"),
+            "valu_instructions_per_wave_ray": rec["derived"].get("valu_wave_instr_per_wave_ray"),
+            "lds_busy": rec["derived"].get("lds_busy_fraction"),
+            "clock_ghz_under_profile": rec["derived"].get("clock_ghz"),
+            "traffic": rec["derived"].get("hbm_bytes_per_launch"),
+            "recorded_kernel_ms": rec["derived"].get("kernel_ms"),
+        })
+    return out
+
+
+def host_threads():
+    """Host threads this process may use: the box's share (OMP_NUM_THREADS is set to it there), else the CPUs this
+    process is allowed on."""
+    try:
+        n = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        n = 0
+    return n if n > 0 else len(os.sched_getaffinity(0))
 
 
 def main():
@@ -175,8 +279,10 @@ def main():
     ap.add_argument("--workload", default="cfg4")
     ap.add_argument("--width", type=int, default=None, help="reduced frame width (debugging)")
     ap.add_argument("--height", type=int, default=None, help="reduced frame height (debugging)")
+    ap.add_argument("--screen", type=int, default=4, help="cap of the screen level (0 = the exact double loop only)")
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the frame the CPU baseline traces")
-    ap.add_argument("--cpu-cores", type=int, default=16)
+    ap.add_argument("--cpu-cores", type=int, default=None, help="host threads of the CPU baseline (default: all this "
+                    "process may use)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-frame512", action="store_true")
     ap.add_argument("--chunks", type=int, default=None,
@@ -198,6 +304,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     raytracing_amd.init(local)
+    raytracing_amd.set_diagnostic("screen_cap", args.screen)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
@@ -216,11 +323,11 @@ def main():
     torch.cuda.set_stream(torch_stream)
     stream = torch_stream.cuda_stream
 
-    def step(count=False):
+    def step(count=False, stats=None):
         def trace(first, rows, piece):
             job.trace(first, rows, GRAFT_OUT_F32_RGBA, piece.data_ptr(), None, counters.data_ptr() if count else None,
                       stream)
-        trace_and_gather(trace, band, frame, H, world, rank, args.chunks)
+        trace_and_gather(trace, band, frame, H, world, rank, args.chunks, stats=stats)
 
     def fence():
         torch.cuda.synchronize()
@@ -235,12 +342,13 @@ def main():
     if world > 1:
         dist.all_reduce(stats)
     rays, tests = int(stats[0]), int(stats[1])
-    local_tests = int(counters[1])
+    local_rays, local_tests = int(counters[0]), int(counters[1])
 
     for _ in range(args.warmup):
         step()
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    per_step = [dict() for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         if world == 1:  # one launch per frame: its HIP-event time is the kernel time of the roofline
@@ -249,7 +357,7 @@ def main():
             ev[k][1].record()
         else:           # pieces of the band are traced and shipped to rank 0 in a pipeline
             ev[k][0].record()
-            step()
+            step(stats=per_step[k])
             ev[k][1].record()
     fence()
     elapsed = time.perf_counter() - t0
@@ -259,51 +367,67 @@ def main():
     elapsed = float(t[0])
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
+    per_rank = None
+    if world > 1:
+        # what every rank did per frame: its rays, the device time of its own kernels (first launch to last kernel
+        # done), the host time spent waiting for transfers after the last kernel was queued, and the whole step
+        mine = torch.tensor([local_rays,
+                             sum(d["trace_event"][0].elapsed_time(d["trace_event"][1]) for d in per_step) / args.steps,
+                             sum(d["wait_s"] for d in per_step) / args.steps * 1e3, kernel_ms,
+                             sum(d["pieces"] for d in per_step) / args.steps], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [{"rank": r, "rays": int(g[0]), "trace_ms": float(g[1]), "transfer_wait_ms": float(g[2]),
+                     "step_ms": float(g[3]), "pieces": int(g[4])} for r, g in enumerate(gathered)]
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        achieved = FLOP_PER_TEST * local_tests / (kernel_ms * 1e-3) / 1e12
-        counters_rec = recorded_counters(args.workload, [W, H])
+        rec, note = recorded_counters(args.workload, [W, H], args.screen)
         out = {
             "metric": "Mrays/s", "value": rays / (elapsed / args.steps) / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "config": {"workload": desc, "frame": [W, H], "output": "float4 RGBA in HBM",
+                                            "screen_level": job.screen_level(),
                                             "parallelism": ("1 GPU" if world == 1 else "rows dealt round-robin in %d pieces per GPU x%d, "
                                                             "RCCL send/recv to rank 0 pipelined behind tracing"
                                                             % (args.chunks, world))},
             "rays_per_frame": rays, "tests_per_frame": tests,
             "primary_Msamples_per_s": W * H * (rt.numPasses ** 2 if rt.aliasing else 1) / (elapsed / args.steps) / 1e6,
-            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": PEAK_FP64_VALU, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_VALU, "frac_nofma": achieved / PEAK_FP64_NOFMA,
-                         "traffic": counters_rec.get("hbm_bytes_per_launch"),
-                         "valu_busy": counters_rec.get("valu_busy_fraction"),
-                         "valu_instructions_per_wave_ray": counters_rec.get("valu_instructions_per_wave_ray"),
-                         "kernel": "traceKernel", "kernel_ms": kernel_ms,
-                         "tests_per_launch": local_tests, "flop_per_test": FLOP_PER_TEST,
-                         "note": "achieved counts the 17 flop of the reference's brute-force test for every "
-                                 "(ray, shape) pair; the kernel proves most pairs to be misses with cheaper "
-                                 "single-precision screens, so achieved can exceed the FP64 peak; valu_busy is the "
-                                 "measured fraction of cycles the vector ALUs issue (profiles/)"},
+            "kernel_source_hash": kernel_source_hash(),
         }
-        if world > 1:  # the assembled frame against rank 0's own trace of 16 tile rows spread over all pieces
+        if world == 1:
+            out["roofline"] = roofline(rec, note, kernel_ms, local_tests)
+        else:  # the per-launch kernel time is not isolated here; the 1-GPU line carries the roofline
+            out["roofline"] = {"bound": "valu_fp64", "achieved": None, "peak": PEAK_FP64_VALU, "unit": "TFLOP/s",
+                               "frac": None, "traffic": None, "kernel": "traceKernel",
+                               "note": "see the 1-GPU line: at N > 1 a step is several launches per rank"}
+            mean_rays = rays / world
+            out["per_rank"] = per_rank
+            out["ray_imbalance"] = max(p["rays"] for p in per_rank) / mean_rays
             torch.cuda.synchronize()
+            # the assembled frame against rank 0's own trace of 64 tile rows spread over all pieces
             check = torch.empty((8, W, 4), dtype=torch.float32, device=dev)
-            same = True
-            for i in range(16):
-                r = min(int((i + 0.5) * H / 16) // 8 * 8, max(H - 8, 0))
+            same, checked = True, 0
+            for i in range(64):
+                r = min(int((i + 0.5) * H / 64) // 8 * 8, max(H - 8, 0))
                 n = min(8, H - r)
                 job.trace(r, n, GRAFT_OUT_F32_RGBA, check.data_ptr(), None, None, stream)
                 torch.cuda.synchronize()
                 same = same and bool(torch.equal(check[:n], frame[r:r + n]))
+                checked += 1
             out["gathered_frame_matches_local_trace"] = same
+            out["gathered_frame_tile_rows_checked"] = checked
         if world == 1 and not args.no_frame512:
             out["frame_512"] = frame_512(dev)
         if world == 1 and not args.no_cpu:
+            cores = args.cpu_cores or host_threads()
             rows = args.cpu_rows
             if rows is None:  # aim at roughly 15 s of CPU work: ~4e8 ray-shape tests/s per host core
                 per_row = max(tests / H, 1.0)
-                rows = int(max(1, min(H, 15.0 * 4.0e8 * args.cpu_cores / per_row)))
-            out["cpu_baseline"] = cpu_baseline(rt, band, row0, n_rows, args.cpu_cores, rows)
+                rows = int(max(1, min(H, 15.0 * 4.0e8 * cores / per_row)))
+            out["cpu_baseline"] = cpu_baseline(rt, band, row0, n_rows, cores, rows)
+            out["cpu_baseline"]["host_cpus_visible"] = os.cpu_count()
             ref = cpu_reference(args.workload)
             if ref is not None:
                 out["cpu_reference"] = ref

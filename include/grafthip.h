@@ -124,6 +124,21 @@ GRAFT_API void graftShutdown(void);
 /* Text of the last error; never NULL. */
 GRAFT_API const char *graftLastError(void);
 
+/* Diagnostic settings: for A/B timing and for the tests that run every kernel variant.  None of them changes a
+ * result.  They start from the environment, which is read ONCE, at the first graftInit or graftDiagnostic* call
+ * (GRAFT_SCREEN, GRAFT_GROUP, GRAFT_PER_TICKET, GRAFT_PARK); afterwards only graftDiagnosticSet changes them, and
+ * graftDiagnosticGet reports the values in force.  A setting applies to jobs created (SCREEN_CAP, GROUP_SIZE) or
+ * traces queued (TILES_PER_TICKET, PARK) after the call.  (No reference counterpart.) */
+enum {
+    GRAFT_DIAG_SCREEN_CAP = 0,       /* 0..4: highest screen level a job may use (graftJobScreenLevel); default 4 */
+    GRAFT_DIAG_GROUP_SIZE = 1,       /* spheres per group of the two-level screens: 0 = chosen per scene, else 4..64, a multiple of 4 */
+    GRAFT_DIAG_TILES_PER_TICKET = 2, /* 8x8 tiles a wave draws from the ticket counters at once: 0 = chosen per launch */
+    GRAFT_DIAG_PARK = 3,             /* 1 (default): one-sample-per-pixel traces of mirror scenes trace their mirror rays in full waves */
+    GRAFT_DIAG_TABLE_BUILDS = 4      /* read-only: screen tables built so far (shows what a re-render re-used) */
+};
+GRAFT_API int graftDiagnosticSet(int which, int value);
+GRAFT_API int graftDiagnosticGet(int which); /* -1 for an unknown setting */
+
 /* ---- host-side steps of launchRays (pure CPU, bit-for-bit the reference's arithmetic) --------------- */
 
 /* The values of `for (double i = -extent/2; i < extent/2; i = i + extent/n)` (mainTracing.c:392-393).
@@ -137,6 +152,14 @@ GRAFT_API int graftScreenCoord(double coord, int n, double extent);
 /* camInitialize (mainTracing.c:375-384) via getNewPoint (:104-114). */
 GRAFT_API void graftCamInitialize(const double target[3], const double viewDir[3], double targetToScreen,
                                   double screenToCam, double screenCenter[3], double camPos[3]);
+
+/* ---- page-locked host memory --------------------------------------------------------------------------- */
+
+/* A host buffer the GPU can copy into directly (hipHostMalloc): a frame buffer allocated here makes the copy back
+ * in graftRenderRows one DMA transfer instead of a staged one.  The launchRays() drop-in keeps its frame in one.
+ * (No reference counterpart: the reference's frame lives inside the display library, 000pixel.h:53-55.) */
+GRAFT_API int graftHostAlloc(size_t bytes, void **out);
+GRAFT_API void graftHostFree(void *p);
 
 /* ---- the path -------------------------------------------------------------------------------------- */
 
@@ -166,10 +189,13 @@ GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void
 /* Block until everything queued on the library's stream has finished. */
 GRAFT_API int graftSynchronize(void);
 
-/* One-shot convenience for host callers: create a job, trace rows [row0,row0+nRows) and copy the result to
- * HOST buffers (frame in `format`; hitIndex and counters optional).  This is what a launchRays() drop-in
- * calls once per frame.  The device-side frame buffers are kept and reused by later calls (grow-only, sized for the
- * largest band rendered so far) until graftShutdown. */
+/* One-shot convenience for host callers: pack and upload scene and view, trace rows [row0,row0+nRows) and copy the
+ * result to HOST buffers (frame in `format`; hitIndex and counters optional).  This is what a launchRays() drop-in
+ * calls once per frame (mainTracing.c:630, :642).  State kept between calls, until graftShutdown: the device-side
+ * frame buffers (grow-only), and the packed job -- a call whose scene, view and settings equal the previous call's
+ * byte for byte packs and uploads nothing; one that differs re-packs into the same device block, re-using the screen
+ * tables whose inputs did not change (a key press that toggles anti-aliasing or depth rebuilds none, one that turns
+ * the view rebuilds the camera's only). */
 GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
                               void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost);
 

@@ -14,6 +14,7 @@ GRAFT_OK, GRAFT_ERR_ARG, GRAFT_ERR_UNSUPPORTED, GRAFT_ERR_HIP, GRAFT_ERR_STATE =
 GRAFT_SPHERE, GRAFT_PLANE = 0, 1
 GRAFT_ORTHOGRAPHIC, GRAFT_PERSPECTIVE = 0, 1
 GRAFT_OUT_F64_RGB, GRAFT_OUT_F32_RGBA, GRAFT_OUT_U8_RGBA = 0, 1, 2
+DIAGNOSTICS = {"screen_cap": 0, "group_size": 1, "tiles_per_ticket": 2, "park": 3, "table_builds": 4}
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
@@ -84,6 +85,11 @@ lib.graftSynchronize.restype = ctypes.c_int
 lib.graftRenderRows.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTER(GraftView), ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 lib.graftWritePPM.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+lib.graftDiagnosticSet.argtypes = [ctypes.c_int, ctypes.c_int]
+lib.graftDiagnosticGet.argtypes = [ctypes.c_int]
+lib.graftHostAlloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+lib.graftHostFree.argtypes = [ctypes.c_void_p]
+lib.graftHostFree.restype = None
 lib.graftPixelBytes.argtypes = [ctypes.c_int]
 lib.graftPixelBytes.restype = ctypes.c_size_t
 lib.graftProbeSqrt.argtypes = [c_double_p, c_double_p, ctypes.c_size_t]

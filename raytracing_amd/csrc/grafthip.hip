@@ -27,6 +27,7 @@
 #include "trace_types.h"
 #include "closest_hit.h"
 #include "pack_tables.h"
+#include "host_job.h"
 
 using namespace graft;
 
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 for (int i = threadIdx.x; i < P.geomDoubles; i += blockDim.x) dd[i] = P.geom[i];
             }
         } else {
-            for (int i = threadIdx.x; i < P.geomDoubles; i += blockDim.x) ldsGeom[i] = P.geom[i];
+            for (int i = threadIdx.x; i < P.geomDoubles + kGeomPad; i += blockDim.x) ldsGeom[i] = P.geom[i];
         }
         __syncthreads();
     }
@@ -468,13 +469,24 @@ __global__ void probeDivKernel(const double *a, const double *b, double *out, si
 // ---------------------------------------------------------------------------------------------------
 
 char gError[512] = "no error";
-int gDevice = -1;
-int gNumCU = 0;
-hipStream_t gStream = nullptr;
 
-// Device buffers graftRenderRows reuses from call to call (an interactive host calls it once per frame with the
-// same sizes): grow-only, released by graftShutdown.  hipMalloc + hipFree cost about as much as tracing a 512x512
-// frame of the reference's start-up scene.
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(gError, sizeof gError, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(GRAFT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// A device buffer that is reused from call to call (an interactive host renders frame after frame with the same
+// sizes): grow-only, released by graftShutdown.  hipMalloc + hipFree cost about as much as tracing a 512x512 frame
+// of the reference's start-up scene.
 struct Reusable {
     void *ptr = nullptr;
     size_t cap = 0;
@@ -493,21 +505,38 @@ struct Reusable {
         cap = 0;
     }
 };
-Reusable gFrameBuf, gIndexBuf, gCounterBuf;
 
-int fail(int code, const char *fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(gError, sizeof gError, fmt, ap);
-    va_end(ap);
-    return code;
+constexpr int kMaxDevices = 16;
+
+// What the library holds per GPU.
+struct Device {
+    bool ready = false;
+    int id = -1, numCU = 0;
+    hipStream_t stream = nullptr;
+    Reusable frame, index, counters;      // device side of graftRenderRows' host buffers
+    Reusable arena;                       // device block of the job graftRenderRows keeps between calls
+    std::vector<unsigned char> cacheKey;  // the input that job was packed from
+    GraftJob *cacheJob = nullptr;
+    std::vector<const void *> configured;  // kernels whose dynamic-LDS limit has been raised on this device
+};
+
+Device gDevices[kMaxDevices];
+Device *gBound = nullptr;  // the device of graftInit: the single-device entry points work on it
+Settings gSettings;
+bool gSettingsRead = false;
+TableCache gTables;
+
+// The diagnostic settings start from the environment, read ONCE (at the first graftInit); afterwards only
+// graftDiagnosticSet changes them.
+void readSettingsOnce() {
+    if (gSettingsRead) return;
+    gSettingsRead = true;
+    if (const char *e = getenv("GRAFT_SCREEN"))
+        if (e[0] >= '0' && e[0] <= '4' && !e[1]) gSettings.screenCap = e[0] - '0';
+    if (const char *e = getenv("GRAFT_GROUP")) gSettings.groupSize = atoi(e);
+    if (const char *e = getenv("GRAFT_PER_TICKET")) gSettings.tilesPerTicket = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char *e = getenv("GRAFT_PARK")) gSettings.park = atoi(e) != 0;
 }
-
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return fail(GRAFT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
 
 typedef void (*TraceFn)(const TraceParams);
 
@@ -522,7 +551,7 @@ TraceFn pickKernelA(bool lds, int screen, bool exactLds) {
 }
 
 // Scenes with a transparent shape run the tree-walk kernels, built only for the general avoid mode, screen
-// levels 0 and 1, and exact doubles in global memory (the jobs are normalised to that in graftJobCreate).
+// levels 0 and 1, and exact doubles in global memory (the jobs are normalised to that in packJob).
 template <bool M>
 TraceFn pickKernelM(int avoidMode, bool lds, int screen, bool exactLds, bool transp) {
     if (transp) {
@@ -547,11 +576,125 @@ struct GraftJob {
     bool lds;
     bool exactLds;  // exact doubles staged in LDS behind the screen table
     bool transp;    // some shape is transparent: tree-walk kernel
+    bool mirrors;   // some shape reflects
     size_t ldsBytes;
     int block;
     int blocksPerCU;  // resident workgroups per CU (occupancy query at the first trace), 0 = not asked yet
-    void *arena;  // one device allocation holding every table
+    void *arena;      // the device block holding every table
+    bool ownsArena;   // false: the block belongs to a Device (graftRenderRows' cached job)
+    Device *dev;
 };
+
+namespace {
+
+void describe(GraftJob *job, const PackedJob &J, void *base, bool owns, Device *dev) {
+    job->P = bindImage(J, base);
+    job->avoidMode = J.avoidMode;
+    job->screen = J.screen;
+    job->lds = J.lds;
+    job->exactLds = J.exactLds;
+    job->transp = J.transp;
+    job->mirrors = J.mirrors;
+    job->ldsBytes = J.ldsBytes;
+    job->block = J.block;
+    job->blocksPerCU = 0;
+    job->arena = base;
+    job->ownsArena = owns;
+    job->dev = dev;
+}
+
+int initDevice(int device, Device **out) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n || device >= kMaxDevices) return fail(GRAFT_ERR_ARG, "device %d of %d", device, n);
+    Device &D = gDevices[device];
+    if (!D.ready) {
+        readSettingsOnce();
+        HIP_TRY(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        D.numCU = prop.multiProcessorCount;
+        HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+        D.id = device;
+        D.ready = true;
+    }
+    *out = &D;
+    return GRAFT_OK;
+}
+
+void releaseDevice(Device &D) {
+    if (!D.ready) return;
+    (void)hipSetDevice(D.id);
+    if (D.stream) {
+        (void)hipStreamSynchronize(D.stream);
+        (void)hipStreamDestroy(D.stream);
+    }
+    delete D.cacheJob;
+    D.cacheJob = nullptr;
+    D.cacheKey.clear();
+    D.frame.release();
+    D.index.release();
+    D.counters.release();
+    D.arena.release();
+    D.configured.clear();
+    D.stream = nullptr;
+    D.ready = false;
+}
+
+// Queue one trace of rows [row0, row0 + nRows) of `job` on stream `s` of the job's device (which must be current).
+int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int32_t *hitIndex, GraftCounters *counters,
+                hipStream_t s) {
+    Device *D = job->dev;
+    TraceParams P = job->P;
+    P.row0 = row0; P.bandRows = nRows; P.format = format;
+    P.frame = frame; P.hitIndex = hitIndex; P.counters = (unsigned long long *)counters;
+    P.tilesX = (P.nCols + kTile - 1) / kTile;
+    const long long tiles = (long long)P.tilesX * ((nRows + kTile - 1) / kTile);
+    if (tiles > 0x7fff0000LL) return fail(GRAFT_ERR_ARG, "graftJobTrace: %lld tiles in one launch", tiles);
+    P.numTiles = (int)tiles;
+    const int wavesPerBlock = job->block / 64;
+    // cheap tiles (few samples per pixel) are drawn several at a time and from several counters
+    const int samples = P.aliasing ? P.numPasses * P.numPasses : 1;
+    const bool manyCursors = samples < 4;
+    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, manyCursors);
+    if (job->lds && std::find(D->configured.begin(), D->configured.end(), (const void *)fn) == D->configured.end()) {
+        // more dynamic LDS than the default limit: raised once per kernel and device, when the kernel is first used
+        HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+        D->configured.push_back((const void *)fn);
+    }
+    if (job->blocksPerCU == 0) {  // persistent grid: as many workgroups as the kernel's registers and LDS let a CU hold
+        int perCU = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)fn, job->block, job->ldsBytes));
+        job->blocksPerCU = perCU < 1 ? 1 : perCU;
+    }
+    const int blocksPerCU = job->blocksPerCU;
+    long long wantBlocks = (tiles + wavesPerBlock - 1) / wavesPerBlock;
+    long long maxBlocks = (long long)D->numCU * blocksPerCU;
+    const int grid = (int)(wantBlocks < maxBlocks ? wantBlocks : maxBlocks);
+    const long long waves = (long long)grid * wavesPerBlock;
+    // tiles per ticket: 1 for expensive tiles, 2 for cheap ones, but never so many that a wave gets fewer than 8 draws
+    // (load balance at the end of the launch)
+    long long perTicket = manyCursors ? 2 : 1;
+    if (perTicket * waves * 8 > tiles) perTicket = tiles / (waves * 8) < 1 ? 1 : tiles / (waves * 8);
+    if (gSettings.tilesPerTicket > 0) perTicket = gSettings.tilesPerTicket;  // diagnostics: forced ticket size
+    P.tilesPerTicket = (int)perTicket;
+    P.prefetchTickets = (tiles + perTicket - 1) / perTicket >= 8 * waves ? 1 : 0;
+    if (manyCursors) HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int) * kCursors * kCursorStride, s));
+    else HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)P.tileCursor, grid * wavesPerBlock, 1, s));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(job->block), job->ldsBytes, s, P);
+    HIP_TRY(hipGetLastError());
+    return GRAFT_OK;
+}
+
+int checkTraceArgs(const char *who, const GraftJob *job, int row0, int nRows, int format, const void *frame) {
+    if (!job || !frame) return fail(GRAFT_ERR_ARG, "%s: null job or frame", who);
+    if (graftPixelBytes(format) == 0) return fail(GRAFT_ERR_ARG, "%s: unknown format %d", who, format);
+    if (row0 < 0 || nRows <= 0 || row0 + nRows > job->P.nRows)
+        return fail(GRAFT_ERR_ARG, "%s: rows [%d,+%d) outside frame of %d rows", who, row0, nRows, job->P.nRows);
+    return GRAFT_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -566,40 +709,56 @@ GRAFT_API int graftDeviceCount(void) {
 }
 
 GRAFT_API int graftInit(int device) {
-    if (gDevice == device && gStream) return GRAFT_OK;
-    if (gDevice >= 0) return fail(GRAFT_ERR_STATE, "graftInit: already bound to device %d", gDevice);
-    int n = 0;
-    HIP_TRY(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n) return fail(GRAFT_ERR_ARG, "graftInit: device %d of %d", device, n);
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    gNumCU = prop.multiProcessorCount;
-    HIP_TRY(hipStreamCreateWithFlags(&gStream, hipStreamNonBlocking));
-    for (int a = 0; a < 3; ++a)
-        for (int f = 0; f < 5; ++f)
-            for (int x = 0; x < 2; ++x)
-                for (int t = 0; t < 2; ++t)
-                    for (int m = 0; m < 2; ++m)
-                        HIP_TRY(hipFuncSetAttribute((const void *)pickKernel(a, true, f, x != 0, t != 0, m != 0),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
-    gDevice = device;
+    if (gBound && gBound->id == device) return GRAFT_OK;
+    if (gBound) return fail(GRAFT_ERR_STATE, "graftInit: already bound to device %d", gBound->id);
+    Device *D = nullptr;
+    const int rc = initDevice(device, &D);
+    if (rc != GRAFT_OK) return rc;
+    gBound = D;
     return GRAFT_OK;
 }
 
 GRAFT_API void graftShutdown(void) {
-    if (gStream) {
-        (void)hipStreamSynchronize(gStream);
-        (void)hipStreamDestroy(gStream);
-    }
-    gFrameBuf.release();
-    gIndexBuf.release();
-    gCounterBuf.release();
-    gStream = nullptr;
-    gDevice = -1;
+    for (Device &D : gDevices) releaseDevice(D);
+    gBound = nullptr;
 }
 
 GRAFT_API const char *graftLastError(void) { return gError; }
+
+GRAFT_API int graftDiagnosticSet(int which, int value) {
+    readSettingsOnce();
+    switch (which) {
+        case GRAFT_DIAG_SCREEN_CAP:
+            if (value < 0 || value > 4) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: screen cap %d", value);
+            gSettings.screenCap = value;
+            return GRAFT_OK;
+        case GRAFT_DIAG_GROUP_SIZE:
+            if (value != 0 && (value < 4 || value > 64 || value % 4)) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: group size %d", value);
+            gSettings.groupSize = value;
+            return GRAFT_OK;
+        case GRAFT_DIAG_TILES_PER_TICKET:
+            if (value < 0) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: tiles per ticket %d", value);
+            gSettings.tilesPerTicket = value;
+            return GRAFT_OK;
+        case GRAFT_DIAG_PARK:
+            gSettings.park = value != 0;
+            return GRAFT_OK;
+        default:
+            return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: unknown setting %d", which);
+    }
+}
+
+GRAFT_API int graftDiagnosticGet(int which) {
+    readSettingsOnce();
+    switch (which) {
+        case GRAFT_DIAG_SCREEN_CAP: return gSettings.screenCap;
+        case GRAFT_DIAG_GROUP_SIZE: return gSettings.groupSize;
+        case GRAFT_DIAG_TILES_PER_TICKET: return gSettings.tilesPerTicket;
+        case GRAFT_DIAG_PARK: return gSettings.park;
+        case GRAFT_DIAG_TABLE_BUILDS: return (int)(gTables.builds & 0x7fffffff);
+        default: return -1;
+    }
+}
 
 GRAFT_API int graftWritePPM(const char *path, const void *frameHost, int format, int nCols, int nRows) {
     if (!path || !frameHost || nCols <= 0 || nRows <= 0 || graftPixelBytes(format) == 0)
@@ -668,248 +827,45 @@ GRAFT_API void graftCamInitialize(const double target[3], const double viewDir[3
     for (int c = 0; c < 3; ++c) screenCenter[c] = sc[c];
 }
 
+// ---- pinned host memory ----
+
+GRAFT_API int graftHostAlloc(size_t bytes, void **out) {
+    if (!out || bytes == 0) return fail(GRAFT_ERR_ARG, "graftHostAlloc: null pointer or zero size");
+    *out = nullptr;
+    if (!gBound) return fail(GRAFT_ERR_STATE, "graftHostAlloc: call graftInit first");
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return GRAFT_OK;
+}
+
+GRAFT_API void graftHostFree(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 // ---- jobs ----
 
 GRAFT_API int graftJobCreate(const GraftScene *scene, const GraftView *view, GraftJob **jobOut) {
     if (!jobOut) return fail(GRAFT_ERR_ARG, "graftJobCreate: null job pointer");
     *jobOut = nullptr;
-    if (gDevice < 0) return fail(GRAFT_ERR_STATE, "graftJobCreate: call graftInit first");
-    if (!scene || !view) return fail(GRAFT_ERR_ARG, "graftJobCreate: null scene or view");
-    const int nS = scene->numShapes, nL = scene->numLights;
-    if (nS < 0 || nL < 0 || (nS > 0 && !scene->shapes) || (nL > 0 && !scene->lights))
-        return fail(GRAFT_ERR_ARG, "graftJobCreate: bad shape/light arrays (%d shapes, %d lights)", nS, nL);
-    if (view->nCols <= 0 || view->nRows <= 0 || !view->colOffsets || !view->rowOffsets)
-        return fail(GRAFT_ERR_ARG, "graftJobCreate: bad frame %d x %d", view->nCols, view->nRows);
-    if (view->aliasing && view->numPasses < 1)
-        return fail(GRAFT_ERR_ARG, "graftJobCreate: numPasses %d with anti-aliasing on", view->numPasses);
-    if (view->aliasing && view->numPasses > 1024)
-        return fail(GRAFT_ERR_ARG, "graftJobCreate: numPasses %d too large", view->numPasses);
-    if (scene->maxDepth > kMaxDepth)
-        return fail(GRAFT_ERR_UNSUPPORTED, "graftJobCreate: maxDepth %d > %d", scene->maxDepth, kMaxDepth);
-
-    bool transparent = false;
-    std::vector<DevRun> runs;
-    std::vector<DevMaterial> mats(nS);
-    std::vector<double> sph, pln;
-    for (int k = 0; k < nS; ++k) {
-        const GraftShape &s = scene->shapes[k];
-        if (s.kind != GRAFT_SPHERE && s.kind != GRAFT_PLANE)
-            return fail(GRAFT_ERR_ARG, "graftJobCreate: shape %d has kind %d", k, s.kind);
-        if (s.transparency > 0) transparent = true;
-        int slot;
-        if (s.kind == GRAFT_SPHERE) {
-            slot = (int)(sph.size() / 4);
-            sph.insert(sph.end(), {s.geom[0], s.geom[1], s.geom[2], s.geom[3] * s.geom[3]});  // shapes.c:54 radius*radius
-        } else {
-            slot = (int)(pln.size() / 6);
-            pln.insert(pln.end(), s.geom, s.geom + 6);
-        }
-        if (runs.empty() || runs.back().kind != s.kind) runs.push_back({s.kind, k, 0, slot, 0, 0, {0, 0}});
-        runs.back().count++;
-        DevMaterial &m = mats[k];
-        for (int c = 0; c < 3; ++c) m.color[c] = s.color[c];
-        m.reflectivity = s.reflectivity; m.ambientLight = s.ambientLight;
-        m.transparency = s.transparency; m.refrIndex = s.refrIndex;
-        m.slot = slot; m.kind = s.kind;
-    }
-    // avoid lists: contains() (mainTracing.c:116-123) is set membership by pointer identity; entries that
-    // name no shape of the scene can never match
-    int avoidMode = 0;
-    std::vector<DevLight> lights(nL);
-    std::vector<unsigned char> mask((size_t)nL * (nS > 0 ? nS : 1) + 1, 0);
-    for (int i = 0; i < nL; ++i) {
-        const GraftLight &l = scene->lights[i];
-        if (l.avoidNum < 0 || l.avoidOffset < 0 || l.avoidOffset + l.avoidNum > scene->avoidIndexLen ||
-            (l.avoidNum > 0 && !scene->avoidIndex))
-            return fail(GRAFT_ERR_ARG, "graftJobCreate: light %d avoid slice [%d,+%d) outside %d", i, l.avoidOffset,
-                        l.avoidNum, scene->avoidIndexLen);
-        DevLight &d = lights[i];
-        memset(&d, 0, sizeof d);
-        for (int c = 0; c < 3; ++c) { d.color[c] = l.color[c]; d.loc[c] = l.loc[c]; }
-        d.avoidFirst = -1;
-        for (int a = 0; a < l.avoidNum; ++a) {
-            const int s = scene->avoidIndex[l.avoidOffset + a];
-            if (s < 0 || s >= nS || mask[(size_t)i * nS + s]) continue;
-            mask[(size_t)i * nS + s] = 1;
-            if (d.avoidNum++ == 0) d.avoidFirst = s;
-        }
-        if (d.avoidNum == 1 && avoidMode < 1) avoidMode = 1;
-        if (d.avoidNum > 1) avoidMode = 2;
-    }
-
+    if (!gBound) return fail(GRAFT_ERR_STATE, "graftJobCreate: call graftInit first");
+    PackedJob J;
+    std::string err;
+    const int rc = packJob(scene, view, gSettings, gTables, J, err);
+    if (rc != GRAFT_OK) return fail(rc, "graftJobCreate: %s", err.c_str());
     GraftJob *job = new (std::nothrow) GraftJob();
     if (!job) return fail(GRAFT_ERR_HIP, "graftJobCreate: out of host memory");
-    TraceParams &P = job->P;
-    memset(&P, 0, sizeof P);
-    DevCamera cam;
-    memset(&cam, 0, sizeof cam);
-    for (int c = 0; c < 3; ++c) {
-        cam.screenCenter[c] = view->screenCenter[c]; cam.camPos[c] = view->camPos[c]; cam.viewDir[c] = view->viewDir[c];
-        cam.lrVec[c] = view->lrVec[c]; cam.udVec[c] = view->udVec[c]; cam.background[c] = scene->backgroundColor[c];
-    }
-    cam.lrDen = cam.lrVec[0] * cam.lrVec[0] + cam.lrVec[1] * cam.lrVec[1] + cam.lrVec[2] * cam.lrVec[2];
-    cam.udDen = cam.udVec[0] * cam.udVec[0] + cam.udVec[1] * cam.udVec[1] + cam.udVec[2] * cam.udVec[2];
-    cam.subStepX = view->subStepX; cam.subStepY = view->subStepY;
-    P.projectionType = view->projectionType; P.aliasing = view->aliasing ? 1 : 0;
-    P.numPasses = view->numPasses; P.maxDepth = scene->maxDepth;
-    P.numShapes = nS; P.numLights = nL; P.numRuns = (int)runs.size(); P.numSpheres = (int)(sph.size() / 4);
-    P.nCols = view->nCols; P.nRows = view->nRows;
-    P.geomDoubles = (int)(sph.size() + pln.size());
-
-    // GRAFT_SCREEN in the environment caps the screen level (diagnostics and A/B timing): 0 = exact double loop
-    // only, 1 = single-precision screen per sphere, 2 = two-level ball screen, 3 (default) = per-family two-level
-    // screens; each level is used only where the scene qualifies for it
-    const char *env = getenv("GRAFT_SCREEN");
-    const int screenCap = env && env[0] >= '0' && env[0] <= '4' ? env[0] - '0' : 4;
-    int screen = (screenCap >= 1 && !sph.empty()) ? 1 : 0;
-    if (transparent) avoidMode = 2;  // the tree-walk kernels exist for the general avoid mode only
-    std::vector<float> tableF;
-    std::vector<int> memberShape;
-    TwoLevelTable balls;
-    // Spheres per group of the two-level screens (GRAFT_GROUP overrides: diagnostics).  Larger groups halve the
-    // scan over the group entries at the price of more member tests per opened group: measured on 1024 spheres,
-    // 16 per group is 17 % faster than 8 (12: +11 %, 24: +14 %, 32: +11 %), on 256 spheres there is no difference,
-    // and the three-level walk of scenes too large for LDS (members in global memory) is fastest with 8.
-    int groupSize = kGroup;
-    {
-        const size_t n = sph.size() / 4;
-        const size_t F = nL <= 7 ? (size_t)nL + (view->projectionType == GRAFT_PERSPECTIVE ? 1 : 0) + 1 : 1;
-        const size_t nGroups = (n + 15) / 16, groupEntries = (nGroups + 7) / 8 * 8;
-        if (n >= 512 && 16 * F * (groupEntries + 8 + nGroups * 16 + 8) <= kLdsMax) groupSize = 16;
-    }
-    const char *groupEnv = getenv("GRAFT_GROUP");
-    if (groupEnv && groupEnv[0]) {
-        const int want = atoi(groupEnv);
-        if (want >= 4 && want <= 64 && want % 4 == 0) groupSize = want;
-    }
-    P.groupSize = groupSize;
-    if (screen && screenCap >= 2 && pln.empty() && !transparent && packBallTable(sph, groupSize, balls)) {
-        screen = 2;
-        tableF = balls.entries;
-        memberShape = balls.memberShape;
-        P.groupEntries = balls.groupEntries;
-        P.memberBase = balls.memberBase;
-    }
-    // per-family tables: cones seen from the camera (perspective only) and from every light, then the ball table
-    if (screen == 2 && screenCap >= 3 && nL <= 7) {
-        std::vector<std::array<double, 3>> apexes;
-        if (view->projectionType == GRAFT_PERSPECTIVE) apexes.push_back({view->camPos[0], view->camPos[1], view->camPos[2]});
-        const int lightBase = (int)apexes.size();
-        for (int i = 0; i < nL; ++i) apexes.push_back({lights[i].loc[0], lights[i].loc[1], lights[i].loc[2]});
-        // scale: the largest |.|_1 of anything a screened ray can start from or aim at
-        double scale = 0, offs = fabs(view->subStepX) * (view->numPasses + 1) + fabs(view->subStepY) * (view->numPasses + 1);
-        double colMax = 0, rowMax = 0;
-        for (int i = 0; i < view->nCols; ++i) colMax = fmax(colMax, fabs(view->colOffsets[i]));
-        for (int i = 0; i < view->nRows; ++i) rowMax = fmax(rowMax, fabs(view->rowOffsets[i]));
-        scale = fabs(view->screenCenter[0]) + fabs(view->screenCenter[1]) + fabs(view->screenCenter[2]) + 2 * (colMax + rowMax + offs);
-        for (size_t k = 0; k < sph.size() / 4; ++k)
-            scale = fmax(scale, fabs(sph[4 * k]) + fabs(sph[4 * k + 1]) + fabs(sph[4 * k + 2]) + sqrt(sph[4 * k + 3]));
-        for (const auto &a : apexes) scale = fmax(scale, fabs(a[0]) + fabs(a[1]) + fabs(a[2]));
-        if (!apexes.empty() && scale < kGroupScale) {  // (NaN fails the comparison)
-            std::vector<TwoLevelTable> fam(apexes.size() + 1);
-            for (size_t f = 0; f < apexes.size(); ++f) packConeTable(sph, apexes[f].data(), scale, groupSize, fam[f]);
-            fam.back() = balls;
-            std::vector<float> inter;
-            std::vector<int> interShape;
-            interleaveFamilies(fam, inter, interShape);
-            const size_t headFloats = 4 * (size_t)balls.memberBase * fam.size();
-            const size_t ballMemberFloats = balls.entries.size() - 4 * (size_t)balls.memberBase;
-            std::vector<float> supers;
-            interleaveSupers(fam, supers);
-            if (sizeof(float) * inter.size() <= kLdsMax) {
-                screen = 3;
-            } else if (screenCap >= 4 && sizeof(float) * (headFloats + ballMemberFloats + supers.size()) <= kLdsMax) {
-                // cone member sections stay in global memory; the ball family's member section and the third-level
-                // sections are appended to the table so that the kernel can stage them behind the group sections
-                screen = 4;
-                P.ldsHeadFloats = (int)headFloats;
-                P.ballMembersLds = (int)(headFloats / 4);
-                P.ldsTailSrc = (int)inter.size();
-                P.ldsTailFloats = (int)(ballMemberFloats + supers.size());
-                P.superLds = (int)((headFloats + ballMemberFloats) / 4);
-                P.superEntries = balls.superEntries;
-                inter.insert(inter.end(), balls.entries.begin() + 4 * (size_t)balls.memberBase, balls.entries.end());
-                inter.insert(inter.end(), supers.begin(), supers.end());
-            }
-            if (screen >= 3) {
-                tableF.swap(inter);
-                memberShape.swap(interShape);
-                P.families = (int)fam.size();
-                P.ballFamily = (int)fam.size() - 1;
-                P.cameraFamily = lightBase ? 0 : -1;
-                P.lightFamilyBase = lightBase;
-                P.familyScale = scale;
-            }
-        }
-    }
-    if (screen < 2) { P.groupEntries = 0; P.memberBase = 0; memberShape.clear(); }
-    if (screen == 1) packScreenTable(sph, runs, tableF);
-    P.filterFloats = (int)tableF.size();
-
-    // one arena: geometry | float table | runs | materials | lights | mask | colOff | rowOff | camera | cursor+counters
-    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t oGeom = 0, oGeomF = align(oGeom + sizeof(double) * (P.geomDoubles + 1));
-    size_t oMember = align(oGeomF + sizeof(float) * (tableF.size() + 1));
-    size_t oRuns = align(oMember + sizeof(int) * (memberShape.size() + 1));
-    size_t oMat = align(oRuns + sizeof(DevRun) * (runs.size() + 1));
-    size_t oLights = align(oMat + sizeof(DevMaterial) * (nS + 1));
-    size_t oMask = align(oLights + sizeof(DevLight) * (nL + 1));
-    size_t oCol = align(oMask + mask.size() + 1);
-    size_t oRow = align(oCol + sizeof(double) * view->nCols);
-    size_t oCam = align(oRow + sizeof(double) * view->nRows);
-    size_t oCursor = align(oCam + sizeof(DevCamera));
-    size_t total = oCursor + sizeof(int) * kCursors * kCursorStride + 256;
-    std::vector<unsigned char> host(total, 0);
-    if (!sph.empty()) memcpy(&host[oGeom], sph.data(), sizeof(double) * sph.size());
-    if (!pln.empty()) memcpy(&host[oGeom + sizeof(double) * sph.size()], pln.data(), sizeof(double) * pln.size());
-    if (!tableF.empty()) memcpy(&host[oGeomF], tableF.data(), sizeof(float) * tableF.size());
-    if (!memberShape.empty()) memcpy(&host[oMember], memberShape.data(), sizeof(int) * memberShape.size());
-    if (!runs.empty()) memcpy(&host[oRuns], runs.data(), sizeof(DevRun) * runs.size());
-    if (nS) memcpy(&host[oMat], mats.data(), sizeof(DevMaterial) * nS);
-    if (nL) memcpy(&host[oLights], lights.data(), sizeof(DevLight) * nL);
-    if (!mask.empty()) memcpy(&host[oMask], mask.data(), mask.size());
-    memcpy(&host[oCol], view->colOffsets, sizeof(double) * view->nCols);
-    memcpy(&host[oRow], view->rowOffsets, sizeof(double) * view->nRows);
-    memcpy(&host[oCam], &cam, sizeof cam);
-
-    hipError_t e = hipMalloc(&job->arena, total);
+    void *arena = nullptr;
+    hipError_t e = hipMalloc(&arena, J.image.size());
     if (e != hipSuccess) {
         delete job;
-        return fail(GRAFT_ERR_HIP, "hipMalloc(%zu): %s", total, hipGetErrorString(e));
+        return fail(GRAFT_ERR_HIP, "hipMalloc(%zu): %s", J.image.size(), hipGetErrorString(e));
     }
-    e = hipMemcpy(job->arena, host.data(), total, hipMemcpyHostToDevice);
+    e = hipMemcpy(arena, J.image.data(), J.image.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        (void)hipFree(job->arena);
+        (void)hipFree(arena);
         delete job;
         return fail(GRAFT_ERR_HIP, "hipMemcpy(scene): %s", hipGetErrorString(e));
     }
-    unsigned char *base = (unsigned char *)job->arena;
-    P.geom = (const double *)(base + oGeom);
-    P.geomF = (const float *)(base + oGeomF);
-    P.memberShape = (const int *)(base + oMember);
-    P.runs = (const DevRun *)(base + oRuns);
-    P.materials = (const DevMaterial *)(base + oMat);
-    P.lights = (const DevLight *)(base + oLights);
-    P.avoidMask = (const unsigned char *)(base + oMask);
-    P.colOff = (const double *)(base + oCol);
-    P.rowOff = (const double *)(base + oRow);
-    P.camera = (const DevCamera *)(base + oCam);
-    P.tileCursor = (int *)(base + oCursor);
-
-    job->avoidMode = avoidMode;
-    job->blocksPerCU = 0;
-    job->screen = screen;
-    const size_t tableBytes = screen == 4 ? sizeof(float) * ((size_t)P.ldsHeadFloats + P.ldsTailFloats)
-                            : screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)P.geomDoubles;
-    const size_t exactBytes = sizeof(double) * (size_t)P.geomDoubles;
-    job->lds = tableBytes <= kLdsMax;
-    job->transp = transparent;
-    job->exactLds = !transparent && job->lds && screen && screen != 4 &&
-                    ((tableBytes + 31) & ~(size_t)31) + exactBytes <= kLdsMax;
-    P.exactLdsOffset = (int)((tableBytes + 31) & ~(size_t)31);
-    job->ldsBytes = !job->lds ? 0 : job->exactLds ? P.exactLdsOffset + exactBytes : tableBytes;
-    // workgroup size: as many workgroups per CU as the LDS footprint allows, 16 waves per CU in every case
-    job->block = job->ldsBytes <= kLdsSmall ? kSmallBlock : job->ldsBytes <= 2 * kLdsSmall ? 2 * kSmallBlock : kLargeBlock;
+    describe(job, J, arena, true, gBound);
     *jobOut = job;
     return GRAFT_OK;
 }
@@ -918,100 +874,91 @@ GRAFT_API int graftJobScreenLevel(const GraftJob *job) { return job ? job->scree
 
 GRAFT_API void graftJobDestroy(GraftJob *job) {
     if (!job) return;
-    if (gStream) (void)hipStreamSynchronize(gStream);
-    (void)hipFree(job->arena);
+    if (job->dev && job->dev->stream) (void)hipStreamSynchronize(job->dev->stream);
+    if (job->ownsArena) (void)hipFree(job->arena);
     delete job;
 }
 
 GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int32_t *hitIndex,
                             GraftCounters *counters, void *stream) {
-    if (!job || !frame) return fail(GRAFT_ERR_ARG, "graftJobTrace: null job or frame");
-    if (gDevice < 0) return fail(GRAFT_ERR_STATE, "graftJobTrace: call graftInit first");
-    if (graftPixelBytes(format) == 0) return fail(GRAFT_ERR_ARG, "graftJobTrace: unknown format %d", format);
-    if (row0 < 0 || nRows <= 0 || row0 + nRows > job->P.nRows)
-        return fail(GRAFT_ERR_ARG, "graftJobTrace: rows [%d,+%d) outside frame of %d rows", row0, nRows, job->P.nRows);
-    hipStream_t s = stream ? (hipStream_t)stream : gStream;
-    TraceParams P = job->P;
-    P.row0 = row0; P.bandRows = nRows; P.format = format;
-    P.frame = frame; P.hitIndex = hitIndex; P.counters = (unsigned long long *)counters;
-    P.tilesX = (P.nCols + kTile - 1) / kTile;
-    const long long tiles = (long long)P.tilesX * ((nRows + kTile - 1) / kTile);
-    if (tiles > 0x7fff0000LL) return fail(GRAFT_ERR_ARG, "graftJobTrace: %lld tiles in one launch", tiles);
-    P.numTiles = (int)tiles;
-    const int wavesPerBlock = job->block / 64;
-    // cheap tiles (few samples per pixel) are drawn several at a time and from several counters
-    const int samples = P.aliasing ? P.numPasses * P.numPasses : 1;
-    const bool manyCursors = samples < 4;
-    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, manyCursors);
-    if (job->blocksPerCU == 0) {  // persistent grid: as many workgroups as the kernel's registers and LDS let a CU hold
-        int perCU = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)fn, job->block, job->ldsBytes));
-        job->blocksPerCU = perCU < 1 ? 1 : perCU;
-    }
-    const int blocksPerCU = job->blocksPerCU;
-    long long wantBlocks = (tiles + wavesPerBlock - 1) / wavesPerBlock;
-    long long maxBlocks = (long long)gNumCU * blocksPerCU;
-    const int grid = (int)(wantBlocks < maxBlocks ? wantBlocks : maxBlocks);
-    const long long waves = (long long)grid * wavesPerBlock;
-    // tiles per ticket: 1 for expensive tiles, 2 for cheap ones, but never so many that a wave gets fewer than 8 draws
-    // (load balance at the end of the launch)
-    long long perTicket = manyCursors ? 2 : 1;
-    if (perTicket * waves * 8 > tiles) perTicket = tiles / (waves * 8) < 1 ? 1 : tiles / (waves * 8);
-    if (getenv("GRAFT_PER_TICKET"))  // diagnostics: force the ticket size
-        perTicket = atoi(getenv("GRAFT_PER_TICKET")) > 0 ? atoi(getenv("GRAFT_PER_TICKET")) : 1;
-    P.tilesPerTicket = (int)perTicket;
-    P.prefetchTickets = (tiles + perTicket - 1) / perTicket >= 8 * waves ? 1 : 0;
-    if (manyCursors) HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int) * kCursors * kCursorStride, s));
-    else HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)P.tileCursor, grid * wavesPerBlock, 1, s));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(job->block), job->ldsBytes, s, P);
-    HIP_TRY(hipGetLastError());
-    return GRAFT_OK;
+    if (!gBound) return fail(GRAFT_ERR_STATE, "graftJobTrace: call graftInit first");
+    const int rc = checkTraceArgs("graftJobTrace", job, row0, nRows, format, frame);
+    if (rc != GRAFT_OK) return rc;
+    return launchTrace(job, row0, nRows, format, frame, hitIndex, counters, stream ? (hipStream_t)stream : job->dev->stream);
 }
 
 GRAFT_API int graftSynchronize(void) {
-    if (gDevice < 0) return fail(GRAFT_ERR_STATE, "graftSynchronize: call graftInit first");
-    HIP_TRY(hipStreamSynchronize(gStream));
+    if (!gBound) return fail(GRAFT_ERR_STATE, "graftSynchronize: call graftInit first");
+    HIP_TRY(hipStreamSynchronize(gBound->stream));
+    return GRAFT_OK;
+}
+
+// The job graftRenderRows traces: the one of the previous call when scene, view and settings are byte for byte the
+// same (nothing is packed or uploaded then), otherwise a new one packed into the same device block.
+static int cachedJob(Device *D, const GraftScene *scene, const GraftView *view, GraftJob **out) {
+    if (!scene || !view) return fail(GRAFT_ERR_ARG, "graftRenderRows: null scene or view");
+    if (view->nCols <= 0 || view->nRows <= 0 || !view->colOffsets || !view->rowOffsets)
+        return fail(GRAFT_ERR_ARG, "graftRenderRows: bad frame %d x %d", view->nCols, view->nRows);
+    std::vector<unsigned char> key;
+    jobKey(scene, view, gSettings, key);
+    if (D->cacheJob && key == D->cacheKey) {
+        *out = D->cacheJob;
+        return GRAFT_OK;
+    }
+    PackedJob J;
+    std::string err;
+    const int rc = packJob(scene, view, gSettings, gTables, J, err);
+    if (rc != GRAFT_OK) return fail(rc, "graftJobCreate: %s", err.c_str());
+    D->cacheKey.clear();  // whatever happens below, the old job's block is about to be overwritten
+    hipError_t e = D->arena.reserve(J.image.size());
+    if (e != hipSuccess) return fail(GRAFT_ERR_HIP, "hipMalloc(%zu): %s", J.image.size(), hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(D->arena.ptr, J.image.data(), J.image.size(), hipMemcpyHostToDevice));
+    if (!D->cacheJob) D->cacheJob = new (std::nothrow) GraftJob();
+    if (!D->cacheJob) return fail(GRAFT_ERR_HIP, "graftRenderRows: out of host memory");
+    describe(D->cacheJob, J, D->arena.ptr, false, D);
+    D->cacheKey.swap(key);
+    *out = D->cacheJob;
     return GRAFT_OK;
 }
 
 GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
                               void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost) {
     if (!frameHost) return fail(GRAFT_ERR_ARG, "graftRenderRows: null frame");
+    if (!gBound) return fail(GRAFT_ERR_STATE, "graftJobCreate: call graftInit first");
+    Device *D = gBound;
     GraftJob *job = nullptr;
-    int rc = graftJobCreate(scene, view, &job);
+    int rc = cachedJob(D, scene, view, &job);
     if (rc != GRAFT_OK) return rc;
     const size_t px = (size_t)(nRows > 0 ? nRows : 0) * job->P.nCols;
     const size_t frameBytes = px * graftPixelBytes(format);
-    void *dFrame = nullptr;
+    if (frameBytes == 0) return fail(GRAFT_ERR_ARG, "graftRenderRows: empty band or unknown format");
+    rc = checkTraceArgs("graftRenderRows", job, row0, nRows, format, frameHost);
+    if (rc != GRAFT_OK) return rc;
+    hipError_t e;
+    if ((e = D->frame.reserve(frameBytes)) != hipSuccess) return fail(GRAFT_ERR_HIP, "hipMalloc(frame, %zu): %s", frameBytes, hipGetErrorString(e));
     int32_t *dIdx = nullptr;
     GraftCounters *dCnt = nullptr;
-    hipError_t e = hipSuccess;
-    if (frameBytes == 0) rc = fail(GRAFT_ERR_ARG, "graftRenderRows: empty band or unknown format");
-    if (rc == GRAFT_OK) {
-        if ((e = gFrameBuf.reserve(frameBytes)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(frame, %zu): %s", frameBytes, hipGetErrorString(e));
-        dFrame = gFrameBuf.ptr;
+    if (hitIndexHost) {
+        if ((e = D->index.reserve(px * 4)) != hipSuccess) return fail(GRAFT_ERR_HIP, "hipMalloc(index): %s", hipGetErrorString(e));
+        dIdx = (int32_t *)D->index.ptr;
     }
-    if (rc == GRAFT_OK && hitIndexHost) {
-        if ((e = gIndexBuf.reserve(px * 4)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(index): %s", hipGetErrorString(e));
-        dIdx = (int32_t *)gIndexBuf.ptr;
+    if (countersHost) {
+        if ((e = D->counters.reserve(sizeof(GraftCounters))) != hipSuccess) return fail(GRAFT_ERR_HIP, "hipMalloc(counters): %s", hipGetErrorString(e));
+        HIP_TRY(hipMemsetAsync(D->counters.ptr, 0, sizeof(GraftCounters), D->stream));
+        dCnt = (GraftCounters *)D->counters.ptr;
     }
-    if (rc == GRAFT_OK && countersHost) {
-        if ((e = gCounterBuf.reserve(sizeof(GraftCounters))) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMalloc(counters): %s", hipGetErrorString(e));
-        else if ((e = hipMemsetAsync(gCounterBuf.ptr, 0, sizeof(GraftCounters), gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
-        dCnt = (GraftCounters *)gCounterBuf.ptr;
-    }
-    if (rc == GRAFT_OK) rc = graftJobTrace(job, row0, nRows, format, dFrame, dIdx, dCnt, nullptr);
-    if (rc == GRAFT_OK && (e = hipMemcpyAsync(frameHost, dFrame, frameBytes, hipMemcpyDeviceToHost, gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(frame): %s", hipGetErrorString(e));
-    if (rc == GRAFT_OK && dIdx && (e = hipMemcpyAsync(hitIndexHost, dIdx, px * 4, hipMemcpyDeviceToHost, gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(index): %s", hipGetErrorString(e));
-    if (rc == GRAFT_OK && dCnt && (e = hipMemcpyAsync(countersHost, dCnt, sizeof(GraftCounters), hipMemcpyDeviceToHost, gStream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(counters): %s", hipGetErrorString(e));
-    if ((e = hipStreamSynchronize(gStream)) != hipSuccess && rc == GRAFT_OK) rc = fail(GRAFT_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
-    graftJobDestroy(job);
+    rc = launchTrace(job, row0, nRows, format, D->frame.ptr, dIdx, dCnt, D->stream);
+    if (rc == GRAFT_OK && (e = hipMemcpyAsync(frameHost, D->frame.ptr, frameBytes, hipMemcpyDeviceToHost, D->stream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(frame): %s", hipGetErrorString(e));
+    if (rc == GRAFT_OK && dIdx && (e = hipMemcpyAsync(hitIndexHost, dIdx, px * 4, hipMemcpyDeviceToHost, D->stream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(index): %s", hipGetErrorString(e));
+    if (rc == GRAFT_OK && dCnt && (e = hipMemcpyAsync(countersHost, dCnt, sizeof(GraftCounters), hipMemcpyDeviceToHost, D->stream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(counters): %s", hipGetErrorString(e));
+    if ((e = hipStreamSynchronize(D->stream)) != hipSuccess && rc == GRAFT_OK) rc = fail(GRAFT_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
     return rc;
 }
 
 static int probe(int which, const double *a, const double *b, double *out, size_t n) {
-    if (gDevice < 0) return fail(GRAFT_ERR_STATE, "probe: call graftInit first");
+    if (!gBound) return fail(GRAFT_ERR_STATE, "probe: call graftInit first");
     if (!a || !out || (which && !b) || n == 0) return fail(GRAFT_ERR_ARG, "probe: null argument");
+    hipStream_t stream = gBound->stream;
     double *dA = nullptr, *dB = nullptr, *dO = nullptr;
     auto run = [&]() -> int {
         HIP_TRY(hipMalloc((void **)&dA, n * 8));
@@ -1022,10 +969,10 @@ static int probe(int which, const double *a, const double *b, double *out, size_
             HIP_TRY(hipMemcpy(dB, b, n * 8, hipMemcpyHostToDevice));
         }
         const unsigned grid = (unsigned)((n + 255) / 256);
-        if (which) hipLaunchKernelGGL(probeDivKernel, dim3(grid), dim3(256), 0, gStream, dA, dB, dO, n);
-        else hipLaunchKernelGGL(probeSqrtKernel, dim3(grid), dim3(256), 0, gStream, dA, dO, n);
+        if (which) hipLaunchKernelGGL(probeDivKernel, dim3(grid), dim3(256), 0, stream, dA, dB, dO, n);
+        else hipLaunchKernelGGL(probeSqrtKernel, dim3(grid), dim3(256), 0, stream, dA, dO, n);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(gStream));
+        HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(out, dO, n * 8, hipMemcpyDeviceToHost));
         return GRAFT_OK;
     };

@@ -1,0 +1,353 @@
+// host_job.h -- host side: turns a GraftScene + GraftView into the image of the one device block a trace kernel
+// reads (geometry, screen tables, materials, lights, loop offsets, camera, ticket counters) plus the launch
+// parameters that go with it.  No HIP call is made here: the caller decides where the image lives (an allocation
+// of its own, a reused buffer, the library's static scratch block).  Included by grafthip.hip only.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <string>
+#include <vector>
+
+#include "trace_types.h"
+#include "pack_tables.h"
+
+namespace graft {
+
+// Diagnostic settings (A/B timing and the tests that run every screen level).  They never change a result.
+struct Settings {
+    int screenCap = 4;       // highest screen level a job may use
+    int groupSize = 0;       // spheres per group of the two-level screens, 0 = chosen per scene
+    int tilesPerTicket = 0;  // tiles a wave draws at once, 0 = chosen per launch
+    int park = 1;            // 1 = launches of one sample per pixel may park mirror rays and trace them in full waves
+};
+
+struct PackedJob {
+    TraceParams P;                     // everything but the pointers, which bindImage() fills in
+    std::vector<unsigned char> image;  // the device block, byte for byte
+    size_t oGeom = 0, oGeomF = 0, oMember = 0, oRuns = 0, oMat = 0, oLights = 0, oMask = 0, oCol = 0, oRow = 0,
+           oCam = 0, oCursor = 0;
+    int avoidMode = 0;
+    int screen = 0;         // 0 = exact only, 1 = screen per sphere, 2 = two-level ball screen, 3/4 = per-family screens
+    bool lds = false;       // hot table staged in LDS
+    bool exactLds = false;  // exact doubles staged in LDS behind the screen table
+    bool transp = false;    // some shape is transparent: tree-walk kernel
+    bool mirrors = false;   // some shape has reflectivity > 0
+    size_t ldsBytes = 0;
+    int block = kSmallBlock;
+};
+
+// Tables that are expensive to build and depend only on part of the input, kept from one packJob to the next: an
+// interactive host re-traces the same scene after every key press (mainTracing.c:552-631), and a key that changes
+// flags, zoom or the view direction leaves the spheres and the lights where they were.  The ball table depends on the
+// sphere geometry and the group size; a cone table on those plus its apex and the (rounded-up) coordinate scale.
+struct TableCache {
+    std::vector<double> sph;
+    int groupSize = -1;
+    bool haveBalls = false, ballsOk = false;
+    TwoLevelTable balls;
+    struct Cone {
+        double apex[3], scale;
+        TwoLevelTable table;
+    };
+    std::list<Cone> cones;  // a list: references handed out stay valid while others are added
+    unsigned long long builds = 0;  // tables built so far (tests and the bench read it through the diagnostics getter)
+
+    void reset(const std::vector<double> &s, int g) {
+        sph = s;
+        groupSize = g;
+        haveBalls = ballsOk = false;
+        cones.clear();
+    }
+    void makeRoom(size_t wanted) {  // call before a round of cone() calls, never between them
+        if (cones.size() + wanted > 32) cones.clear();
+    }
+    const TwoLevelTable &cone(const double apex[3], double scale) {
+        for (Cone &c : cones)
+            if (c.apex[0] == apex[0] && c.apex[1] == apex[1] && c.apex[2] == apex[2] && c.scale == scale) return c.table;
+        cones.emplace_back();
+        Cone &c = cones.back();
+        c.apex[0] = apex[0]; c.apex[1] = apex[1]; c.apex[2] = apex[2];
+        c.scale = scale;
+        packConeTable(sph, apex, scale, groupSize, c.table);
+        builds++;
+        return c.table;
+    }
+};
+
+// Validate, pack shapes to per-kind geometry arrays + materials, avoid lists to indices, and build the screen
+// tables.  Replaces the implicit "read the globals" of launchRays (mainTracing.c:387-391).  Returns a GRAFT_* code
+// and, on failure, a message in `err`.
+inline int packJob(const GraftScene *scene, const GraftView *view, const Settings &set, TableCache &cache,
+                   PackedJob &J, std::string &err) {
+    char msg[256];
+    auto fail = [&](int code, const char *fmt, auto... args) {
+        snprintf(msg, sizeof msg, fmt, args...);
+        err = msg;
+        return code;
+    };
+    if (!scene || !view) return fail(GRAFT_ERR_ARG, "%s", "null scene or view");
+    const int nS = scene->numShapes, nL = scene->numLights;
+    if (nS < 0 || nL < 0 || (nS > 0 && !scene->shapes) || (nL > 0 && !scene->lights))
+        return fail(GRAFT_ERR_ARG, "bad shape/light arrays (%d shapes, %d lights)", nS, nL);
+    if (view->nCols <= 0 || view->nRows <= 0 || !view->colOffsets || !view->rowOffsets)
+        return fail(GRAFT_ERR_ARG, "bad frame %d x %d", view->nCols, view->nRows);
+    if (view->aliasing && view->numPasses < 1)
+        return fail(GRAFT_ERR_ARG, "numPasses %d with anti-aliasing on", view->numPasses);
+    if (view->aliasing && view->numPasses > 1024) return fail(GRAFT_ERR_ARG, "numPasses %d too large", view->numPasses);
+    if (scene->maxDepth > kMaxDepth) return fail(GRAFT_ERR_UNSUPPORTED, "maxDepth %d > %d", scene->maxDepth, kMaxDepth);
+
+    bool transparent = false, mirrors = false;
+    std::vector<DevRun> runs;
+    std::vector<DevMaterial> mats(nS);
+    std::vector<double> sph, pln;
+    for (int k = 0; k < nS; ++k) {
+        const GraftShape &s = scene->shapes[k];
+        if (s.kind != GRAFT_SPHERE && s.kind != GRAFT_PLANE) return fail(GRAFT_ERR_ARG, "shape %d has kind %d", k, s.kind);
+        if (s.transparency > 0) transparent = true;
+        if (s.reflectivity > 0) mirrors = true;
+        int slot;
+        if (s.kind == GRAFT_SPHERE) {
+            slot = (int)(sph.size() / 4);
+            sph.insert(sph.end(), {s.geom[0], s.geom[1], s.geom[2], s.geom[3] * s.geom[3]});  // shapes.c:54 radius*radius
+        } else {
+            slot = (int)(pln.size() / 6);
+            pln.insert(pln.end(), s.geom, s.geom + 6);
+        }
+        if (runs.empty() || runs.back().kind != s.kind) runs.push_back({s.kind, k, 0, slot, 0, 0, {0, 0}});
+        runs.back().count++;
+        DevMaterial &m = mats[k];
+        for (int c = 0; c < 3; ++c) m.color[c] = s.color[c];
+        m.reflectivity = s.reflectivity; m.ambientLight = s.ambientLight;
+        m.transparency = s.transparency; m.refrIndex = s.refrIndex;
+        m.slot = slot; m.kind = s.kind;
+    }
+    // avoid lists: contains() (mainTracing.c:116-123) is set membership by pointer identity; entries that
+    // name no shape of the scene can never match
+    int avoidMode = 0;
+    std::vector<DevLight> lights(nL);
+    std::vector<unsigned char> mask((size_t)nL * (nS > 0 ? nS : 1) + 1, 0);
+    for (int i = 0; i < nL; ++i) {
+        const GraftLight &l = scene->lights[i];
+        if (l.avoidNum < 0 || l.avoidOffset < 0 || l.avoidOffset + l.avoidNum > scene->avoidIndexLen ||
+            (l.avoidNum > 0 && !scene->avoidIndex))
+            return fail(GRAFT_ERR_ARG, "light %d avoid slice [%d,+%d) outside %d", i, l.avoidOffset, l.avoidNum,
+                        scene->avoidIndexLen);
+        DevLight &d = lights[i];
+        memset(&d, 0, sizeof d);
+        for (int c = 0; c < 3; ++c) { d.color[c] = l.color[c]; d.loc[c] = l.loc[c]; }
+        d.avoidFirst = -1;
+        for (int a = 0; a < l.avoidNum; ++a) {
+            const int s = scene->avoidIndex[l.avoidOffset + a];
+            if (s < 0 || s >= nS || mask[(size_t)i * nS + s]) continue;
+            mask[(size_t)i * nS + s] = 1;
+            if (d.avoidNum++ == 0) d.avoidFirst = s;
+        }
+        if (d.avoidNum == 1 && avoidMode < 1) avoidMode = 1;
+        if (d.avoidNum > 1) avoidMode = 2;
+    }
+
+    TraceParams &P = J.P;
+    memset(&P, 0, sizeof P);
+    DevCamera cam;
+    memset(&cam, 0, sizeof cam);
+    for (int c = 0; c < 3; ++c) {
+        cam.screenCenter[c] = view->screenCenter[c]; cam.camPos[c] = view->camPos[c]; cam.viewDir[c] = view->viewDir[c];
+        cam.lrVec[c] = view->lrVec[c]; cam.udVec[c] = view->udVec[c]; cam.background[c] = scene->backgroundColor[c];
+    }
+    cam.lrDen = cam.lrVec[0] * cam.lrVec[0] + cam.lrVec[1] * cam.lrVec[1] + cam.lrVec[2] * cam.lrVec[2];
+    cam.udDen = cam.udVec[0] * cam.udVec[0] + cam.udVec[1] * cam.udVec[1] + cam.udVec[2] * cam.udVec[2];
+    cam.subStepX = view->subStepX; cam.subStepY = view->subStepY;
+    P.projectionType = view->projectionType; P.aliasing = view->aliasing ? 1 : 0;
+    P.numPasses = view->numPasses; P.maxDepth = scene->maxDepth;
+    P.numShapes = nS; P.numLights = nL; P.numRuns = (int)runs.size(); P.numSpheres = (int)(sph.size() / 4);
+    P.nCols = view->nCols; P.nRows = view->nRows;
+    P.geomDoubles = (int)(sph.size() + pln.size());
+
+    const int screenCap = set.screenCap;
+    int screen = (screenCap >= 1 && !sph.empty()) ? 1 : 0;
+    if (transparent) avoidMode = 2;  // the tree-walk kernels exist for the general avoid mode only
+    std::vector<float> tableF;
+    std::vector<int> memberShape;
+    // Spheres per group of the two-level screens.  Larger groups halve the scan over the group entries at the
+    // price of more member tests per opened group: measured on 1024 spheres, 16 per group is 17 % faster than 8
+    // (12: +11 %, 24: +14 %, 32: +11 %), on 256 spheres there is no difference, and the three-level walk of scenes
+    // too large for LDS (members in global memory) is fastest with 8.
+    int groupSize = kGroup;
+    {
+        const size_t n = sph.size() / 4;
+        const size_t F = nL <= 7 ? (size_t)nL + (view->projectionType == GRAFT_PERSPECTIVE ? 1 : 0) + 1 : 1;
+        const size_t nGroups = (n + 15) / 16, groupEntries = (nGroups + 7) / 8 * 8;
+        if (n >= 512 && 16 * F * (groupEntries + 8 + nGroups * 16 + 8) <= kLdsMax) groupSize = 16;
+    }
+    if (set.groupSize >= 4 && set.groupSize <= 64 && set.groupSize % 4 == 0) groupSize = set.groupSize;
+    P.groupSize = groupSize;
+    const bool wantGroups = screen && screenCap >= 2 && pln.empty() && !transparent;
+    const TwoLevelTable *balls = nullptr;
+    if (wantGroups) {
+        if (cache.groupSize != groupSize || cache.sph != sph) cache.reset(sph, groupSize);
+        if (!cache.haveBalls) {
+            cache.ballsOk = packBallTable(sph, groupSize, cache.balls);
+            cache.haveBalls = true;
+            cache.builds++;
+        }
+        if (cache.ballsOk) balls = &cache.balls;
+    }
+    if (balls) {
+        screen = 2;
+        tableF = balls->entries;
+        memberShape = balls->memberShape;
+        P.groupEntries = balls->groupEntries;
+        P.memberBase = balls->memberBase;
+    }
+    // per-family tables: cones seen from the camera (perspective only) and from every light, then the ball table
+    if (screen == 2 && screenCap >= 3 && nL <= 7) {
+        std::vector<std::array<double, 3>> apexes;
+        if (view->projectionType == GRAFT_PERSPECTIVE) apexes.push_back({view->camPos[0], view->camPos[1], view->camPos[2]});
+        const int lightBase = (int)apexes.size();
+        for (int i = 0; i < nL; ++i) apexes.push_back({lights[i].loc[0], lights[i].loc[1], lights[i].loc[2]});
+        // scale: the largest |.|_1 of anything a screened ray can start from or aim at, rounded up to a power of two
+        // (any larger value is valid: it only widens the margins) so that zooming or turning the view leaves the
+        // lights' tables reusable
+        double scale = 0, offs = fabs(view->subStepX) * (view->numPasses + 1) + fabs(view->subStepY) * (view->numPasses + 1);
+        double colMax = 0, rowMax = 0;
+        for (int i = 0; i < view->nCols; ++i) colMax = fmax(colMax, fabs(view->colOffsets[i]));
+        for (int i = 0; i < view->nRows; ++i) rowMax = fmax(rowMax, fabs(view->rowOffsets[i]));
+        scale = fabs(view->screenCenter[0]) + fabs(view->screenCenter[1]) + fabs(view->screenCenter[2]) + 2 * (colMax + rowMax + offs);
+        for (size_t k = 0; k < sph.size() / 4; ++k)
+            scale = fmax(scale, fabs(sph[4 * k]) + fabs(sph[4 * k + 1]) + fabs(sph[4 * k + 2]) + sqrt(sph[4 * k + 3]));
+        for (const auto &a : apexes) scale = fmax(scale, fabs(a[0]) + fabs(a[1]) + fabs(a[2]));
+        if (scale > 0 && scale < kGroupScale) scale = fmax(1.0, exp2(ceil(log2(scale))));  // (NaN stays NaN)
+        if (!apexes.empty() && scale < kGroupScale) {  // (NaN fails the comparison)
+            std::vector<const TwoLevelTable *> fam;
+            cache.makeRoom(apexes.size());
+            for (size_t f = 0; f < apexes.size(); ++f) fam.push_back(&cache.cone(apexes[f].data(), scale));
+            fam.push_back(balls);
+            std::vector<float> inter;
+            std::vector<int> interShape;
+            interleaveFamilies(fam, inter, interShape);
+            const size_t headFloats = 4 * (size_t)balls->memberBase * fam.size();
+            const size_t ballMemberFloats = balls->entries.size() - 4 * (size_t)balls->memberBase;
+            std::vector<float> supers;
+            interleaveSupers(fam, supers);
+            if (sizeof(float) * inter.size() <= kLdsMax) {
+                screen = 3;
+            } else if (screenCap >= 4 && sizeof(float) * (headFloats + ballMemberFloats + supers.size()) <= kLdsMax) {
+                // cone member sections stay in global memory; the ball family's member section and the third-level
+                // sections are appended to the table so that the kernel can stage them behind the group sections
+                screen = 4;
+                P.ldsHeadFloats = (int)headFloats;
+                P.ballMembersLds = (int)(headFloats / 4);
+                P.ldsTailSrc = (int)inter.size();
+                P.ldsTailFloats = (int)(ballMemberFloats + supers.size());
+                P.superLds = (int)((headFloats + ballMemberFloats) / 4);
+                P.superEntries = balls->superEntries;
+                inter.insert(inter.end(), balls->entries.begin() + 4 * (size_t)balls->memberBase, balls->entries.end());
+                inter.insert(inter.end(), supers.begin(), supers.end());
+            }
+            if (screen >= 3) {
+                tableF.swap(inter);
+                memberShape.swap(interShape);
+                P.families = (int)fam.size();
+                P.ballFamily = (int)fam.size() - 1;
+                P.cameraFamily = lightBase ? 0 : -1;
+                P.lightFamilyBase = lightBase;
+                P.familyScale = scale;
+            }
+        }
+    }
+    if (screen < 2) { P.groupEntries = 0; P.memberBase = 0; memberShape.clear(); }
+    if (screen == 1) packScreenTable(sph, runs, tableF);
+    P.filterFloats = (int)tableF.size();
+
+    // one block: geometry | float table | member shapes | runs | materials | lights | mask | colOff | rowOff | camera |
+    // ticket counters.  The geometry is followed by kGeomPad doubles of padding: the exact sphere loop reads one
+    // block of four spheres ahead.
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    J.oGeom = 0;
+    J.oGeomF = align(J.oGeom + sizeof(double) * (P.geomDoubles + kGeomPad));
+    J.oMember = align(J.oGeomF + sizeof(float) * (tableF.size() + 1));
+    J.oRuns = align(J.oMember + sizeof(int) * (memberShape.size() + 1));
+    J.oMat = align(J.oRuns + sizeof(DevRun) * (runs.size() + 1));
+    J.oLights = align(J.oMat + sizeof(DevMaterial) * (nS + 1));
+    J.oMask = align(J.oLights + sizeof(DevLight) * (nL + 1));
+    J.oCol = align(J.oMask + mask.size() + 1);
+    J.oRow = align(J.oCol + sizeof(double) * view->nCols);
+    J.oCam = align(J.oRow + sizeof(double) * view->nRows);
+    J.oCursor = align(J.oCam + sizeof(DevCamera));
+    const size_t total = J.oCursor + sizeof(int) * kCursors * kCursorStride + 256;
+    std::vector<unsigned char> &host = J.image;
+    host.assign(total, 0);
+    if (!sph.empty()) memcpy(&host[J.oGeom], sph.data(), sizeof(double) * sph.size());
+    if (!pln.empty()) memcpy(&host[J.oGeom + sizeof(double) * sph.size()], pln.data(), sizeof(double) * pln.size());
+    for (int i = 0; i < kGeomPad; i += 4) {  // padding spheres that every ray misses: r*r = -inf
+        const double never[4] = {0, 0, 0, -INFINITY};
+        memcpy(&host[J.oGeom + sizeof(double) * (P.geomDoubles + i)], never, sizeof never);
+    }
+    if (!tableF.empty()) memcpy(&host[J.oGeomF], tableF.data(), sizeof(float) * tableF.size());
+    if (!memberShape.empty()) memcpy(&host[J.oMember], memberShape.data(), sizeof(int) * memberShape.size());
+    if (!runs.empty()) memcpy(&host[J.oRuns], runs.data(), sizeof(DevRun) * runs.size());
+    if (nS) memcpy(&host[J.oMat], mats.data(), sizeof(DevMaterial) * nS);
+    if (nL) memcpy(&host[J.oLights], lights.data(), sizeof(DevLight) * nL);
+    if (!mask.empty()) memcpy(&host[J.oMask], mask.data(), mask.size());
+    memcpy(&host[J.oCol], view->colOffsets, sizeof(double) * view->nCols);
+    memcpy(&host[J.oRow], view->rowOffsets, sizeof(double) * view->nRows);
+    memcpy(&host[J.oCam], &cam, sizeof cam);
+
+    J.avoidMode = avoidMode;
+    J.screen = screen;
+    J.mirrors = mirrors;
+    const size_t tableBytes = screen == 4 ? sizeof(float) * ((size_t)P.ldsHeadFloats + P.ldsTailFloats)
+                            : screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)(P.geomDoubles + kGeomPad);
+    const size_t exactBytes = sizeof(double) * (size_t)P.geomDoubles;
+    J.lds = tableBytes <= kLdsMax;
+    J.transp = transparent;
+    J.exactLds = !transparent && J.lds && screen && screen != 4 && ((tableBytes + 31) & ~(size_t)31) + exactBytes <= kLdsMax;
+    P.exactLdsOffset = (int)((tableBytes + 31) & ~(size_t)31);
+    J.ldsBytes = !J.lds ? 0 : J.exactLds ? P.exactLdsOffset + exactBytes : tableBytes;
+    // workgroup size: as many workgroups per CU as the LDS footprint allows, 16 waves per CU in every case
+    J.block = J.ldsBytes <= kLdsSmall ? kSmallBlock : J.ldsBytes <= 2 * kLdsSmall ? 2 * kSmallBlock : kLargeBlock;
+    return GRAFT_OK;
+}
+
+// the launch parameters of a packed job whose image has been copied to device address `base`
+inline TraceParams bindImage(const PackedJob &J, void *base) {
+    TraceParams P = J.P;
+    unsigned char *b = (unsigned char *)base;
+    P.geom = (const double *)(b + J.oGeom);
+    P.geomF = (const float *)(b + J.oGeomF);
+    P.memberShape = (const int *)(b + J.oMember);
+    P.runs = (const DevRun *)(b + J.oRuns);
+    P.materials = (const DevMaterial *)(b + J.oMat);
+    P.lights = (const DevLight *)(b + J.oLights);
+    P.avoidMask = (const unsigned char *)(b + J.oMask);
+    P.colOff = (const double *)(b + J.oCol);
+    P.rowOff = (const double *)(b + J.oRow);
+    P.camera = (const DevCamera *)(b + J.oCam);
+    P.tileCursor = (int *)(b + J.oCursor);
+    return P;
+}
+
+// Everything packJob reads, as bytes: two calls with equal keys produce equal jobs.
+inline void jobKey(const GraftScene *scene, const GraftView *view, const Settings &set, std::vector<unsigned char> &key) {
+    key.clear();
+    auto put = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        key.insert(key.end(), b, b + n);
+    };
+    put(&set, sizeof set);
+    put(&scene->numShapes, sizeof(int32_t)); put(&scene->numLights, sizeof(int32_t));
+    put(&scene->avoidIndexLen, sizeof(int32_t)); put(&scene->maxDepth, sizeof(int32_t));
+    put(scene->backgroundColor, sizeof scene->backgroundColor);
+    if (scene->numShapes > 0 && scene->shapes) put(scene->shapes, sizeof(GraftShape) * (size_t)scene->numShapes);
+    if (scene->numLights > 0 && scene->lights) put(scene->lights, sizeof(GraftLight) * (size_t)scene->numLights);
+    if (scene->avoidIndexLen > 0 && scene->avoidIndex) put(scene->avoidIndex, sizeof(int32_t) * (size_t)scene->avoidIndexLen);
+    put(view, offsetof(GraftView, colOffsets));
+    if (view->nCols > 0 && view->colOffsets) put(view->colOffsets, sizeof(double) * (size_t)view->nCols);
+    if (view->nRows > 0 && view->rowOffsets) put(view->rowOffsets, sizeof(double) * (size_t)view->nRows);
+}
+
+}  // namespace graft

@@ -20,6 +20,24 @@
 #define GRAFT_HEIGHT 512
 #endif
 
+/* The frame the GPU copies into: page-locked, kept from frame to frame (an interactive host traces one after every
+ * key press, mainTracing.c:629-630), grown when the loop runs more iterations (513 per axis after zooming). */
+static double *frameBuffer = NULL;
+static size_t frameBufferBytes = 0;
+
+static double *frame_buffer(size_t bytes) {
+    if (bytes > frameBufferBytes) {
+        void *p = NULL;
+        graftHostFree(frameBuffer);
+        frameBuffer = NULL;
+        frameBufferBytes = 0;
+        if (graftHostAlloc(bytes, &p) != GRAFT_OK) return NULL;
+        frameBuffer = p;
+        frameBufferBytes = bytes;
+    }
+    return frameBuffer;
+}
+
 static int fill_offsets(double extent, int n, double **out) {
     int cap = 2 * n + 32;
     *out = malloc(sizeof(double) * cap);
@@ -90,8 +108,8 @@ void launchRays(void) {
     if (view.nCols <= 0 || view.nRows <= 0) { rc = -2; goto done; }
     view.colOffsets = cols; view.rowOffsets = rows;
 
-    rgb = malloc(sizeof(double) * 3 * (size_t)view.nCols * view.nRows);
-    if (!rgb) { rc = -1; goto done; }
+    rgb = frame_buffer(sizeof(double) * 3 * (size_t)view.nCols * view.nRows);
+    if (!rgb) { rc = GRAFT_ERR_HIP; goto done; }
     rc = graftRenderRows(&scene, &view, 0, view.nRows, GRAFT_OUT_F64_RGB, rgb, NULL, NULL);
     if (rc != GRAFT_OK) goto done;
 
@@ -106,5 +124,5 @@ void launchRays(void) {
 done:
     if (rc != GRAFT_OK) /* the reference has no error channel (void, nothing checked): say so and draw nothing */
         fprintf(stderr, "launchRays (GPU): error %d: %s\n", rc, rc > 0 ? graftLastError() : "host allocation or loop bounds");
-    free(gs); free(gl); free(avoid); free(cols); free(rows); free(rgb);
+    free(gs); free(gl); free(avoid); free(cols); free(rows);
 }

@@ -17,7 +17,7 @@ namespace graft {
 // sphere run gets its own block, padded to a multiple of eight with entries that never pass (rho = -inf), and the
 // table ends with eight more such entries because the hot loop fetches two blocks of four ahead.  Block layout:
 // {cx0 cx1 cy0 cy1}{cz0 cz1 rho0 rho1}{cx2 cx3 cy2 cy3}{cz2 cz3 rho2 rho3}.
-void packScreenTable(const std::vector<double> &sph, std::vector<DevRun> &runs, std::vector<float> &out) {
+inline void packScreenTable(const std::vector<double> &sph, std::vector<DevRun> &runs, std::vector<float> &out) {
     const double u = 5.9604644775390625e-08;
     out.clear();
     auto entry = [&](float *blk, int i, float cx, float cy, float cz, float rho) {
@@ -52,7 +52,7 @@ void packScreenTable(const std::vector<double> &sph, std::vector<DevRun> &runs, 
 
 // rho of the screen table for a ball of squared radius rr centred at c (see packScreenTable); false if the
 // coordinates are not finite or too large for float arithmetic
-bool screenRho(const double c[3], double rr, float &rho) {
+inline bool screenRho(const double c[3], double rr, float &rho) {
     const double u = 5.9604644775390625e-08;
     const double c1 = fabs(c[0]) + fabs(c[1]) + fabs(c[2]);
     if (!(c1 < 1e15 && rr >= 0 && rr < 1e30)) return false;
@@ -62,7 +62,7 @@ bool screenRho(const double c[3], double rr, float &rho) {
     return true;
 }
 
-void putEntry(float *blk, int i, float cx, float cy, float cz, float rho) {
+inline void putEntry(float *blk, int i, float cx, float cy, float cz, float rho) {
     float *pair = blk + 8 * (i >> 1);
     const int h = i & 1;
     pair[0 + h] = cx; pair[2 + h] = cy; pair[4 + h] = cz; pair[6 + h] = rho;
@@ -309,25 +309,25 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
 // family f lands at float4 index 4 * (b * families + f), and the shape index of member entry i at i * families + f.
 // A lane then reads a block with one address and four fixed offsets, and lanes of one wave that trace rays of
 // different families read different 64-byte slots.
-inline void interleaveFamilies(const std::vector<TwoLevelTable> &fam, std::vector<float> &entries,
+inline void interleaveFamilies(const std::vector<const TwoLevelTable *> &fam, std::vector<float> &entries,
                                std::vector<int> &memberShape) {
-    const size_t F = fam.size(), total = fam[0].entries.size() / 4, members = fam[0].memberShape.size();
+    const size_t F = fam.size(), total = fam[0]->entries.size() / 4, members = fam[0]->memberShape.size();
     entries.assign(4 * total * F, 0.0f);
     memberShape.assign(members * F, -1);
     for (size_t f = 0; f < F; ++f) {
         for (size_t e = 0; e < total; ++e)
-            for (int c = 0; c < 4; ++c) entries[4 * (((e / 4) * F + f) * 4 + e % 4) + c] = fam[f].entries[4 * e + c];
-        for (size_t i = 0; i < members; ++i) memberShape[i * F + f] = fam[f].memberShape[i];
+            for (int c = 0; c < 4; ++c) entries[4 * (((e / 4) * F + f) * 4 + e % 4) + c] = fam[f]->entries[4 * e + c];
+        for (size_t i = 0; i < members; ++i) memberShape[i * F + f] = fam[f]->memberShape[i];
     }
 }
 
 // The same interleaving for the third-level sections.
-inline void interleaveSupers(const std::vector<TwoLevelTable> &fam, std::vector<float> &entries) {
-    const size_t F = fam.size(), total = fam[0].supers.size() / 4;
+inline void interleaveSupers(const std::vector<const TwoLevelTable *> &fam, std::vector<float> &entries) {
+    const size_t F = fam.size(), total = fam[0]->supers.size() / 4;
     entries.assign(4 * total * F, 0.0f);
     for (size_t f = 0; f < F; ++f)
         for (size_t e = 0; e < total; ++e)
-            for (int c = 0; c < 4; ++c) entries[4 * (((e / 4) * F + f) * 4 + e % 4) + c] = fam[f].supers[4 * e + c];
+            for (int c = 0; c < 4; ++c) entries[4 * (((e / 4) * F + f) * 4 + e % 4) + c] = fam[f]->supers[4 * e + c];
 }
 
 }  // namespace graft

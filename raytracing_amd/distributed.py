@@ -97,7 +97,7 @@ def local_rows(n_rows, world, rank, chunks):
     return sum(n for _, n, _ in owned_pieces(n_rows, world, rank, chunks))
 
 
-def trace_and_gather(trace, local, frame, n_rows, world, rank, chunks=8, group=None):
+def trace_and_gather(trace, local, frame, n_rows, world, rank, chunks=8, group=None, stats=None):
     """One frame: trace this rank's pieces one by one and ship every finished piece to rank 0 while the next one is
     being traced.  `trace(first_row, rows, tensor)` must queue the kernel that fills `tensor` (the piece's
     [rows][cols][channels] view) on the current stream.  `local` is this rank's [local_rows][cols][channels] buffer
@@ -111,6 +111,11 @@ def trace_and_gather(trace, local, frame, n_rows, world, rank, chunks=8, group=N
     pieces = frame_pieces(n_rows, world, chunks)
     mine = owned_pieces(n_rows, world, rank, chunks)
     works = []
+    if stats is not None:
+        import time
+        import torch
+        first, last = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        first.record()
     for c in range((len(pieces) + world - 1) // world):
         ops = []
         if c < len(mine):
@@ -124,5 +129,10 @@ def trace_and_gather(trace, local, frame, n_rows, world, rank, chunks=8, group=N
                 ops.append(dist.P2POp(dist.irecv, frame[r0:r0 + n], owner, group))
         if ops:
             works.extend(dist.batch_isend_irecv(ops))
+    if stats is not None:
+        last.record()
+        t0 = time.perf_counter()
     for w in works:
         w.wait()
+    if stats is not None:
+        stats.update(trace_event=(first, last), wait_s=time.perf_counter() - t0, pieces=len(mine))

@@ -40,6 +40,19 @@ def device_count():
     return max(n, 0)
 
 
+def set_diagnostic(name, value):
+    """graftDiagnosticSet: "screen_cap" 0..4, "group_size" 0|4..64, "tiles_per_ticket", "park" (A/B timing and tests;
+    no setting changes a result).  Returns the previous value."""
+    which = _lib.DIAGNOSTICS[name]
+    old = lib.graftDiagnosticGet(which)
+    check(lib.graftDiagnosticSet(which, int(value)))
+    return old
+
+
+def get_diagnostic(name):
+    return lib.graftDiagnosticGet(_lib.DIAGNOSTICS[name])
+
+
 def write_ppm(path, frame, fmt=GRAFT_OUT_F64_RGB):
     """Save a host frame ([rows][cols][channels], row 0 at the bottom as pixSetRGB counts) as a binary PPM."""
     a = np.ascontiguousarray(frame)

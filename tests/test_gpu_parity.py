@@ -163,3 +163,35 @@ def test_render_rows_reuses_its_buffers(gpu):
     assert small.last_counters == want["counters"][:2]
     again = big.render_rows()
     assert np.array_equal(first.view(np.uint64), again.view(np.uint64))
+
+
+def test_render_rows_keeps_its_job_and_tables_between_calls(gpu):
+    """graftRenderRows re-uses the packed job when nothing changed and the screen tables whose inputs did not change
+    (what handleKeyDown's re-trace after every key press needs, mainTracing.c:629-630); results stay the oracle's."""
+    from raytracing_amd import get_diagnostic
+    import test_gpu_screens as ts
+    rt = ts.scene(40, 200, lights=3, refl=0.4, depth=3)
+
+    def check():
+        want = ob.render(rt, threads=THREADS, want_index=True)
+        rgb, idx = rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_index=True)
+        assert np.array_equal(idx, want["index"])
+        assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64))
+
+    check()
+    built = get_diagnostic("table_builds")
+    check()                                           # unchanged: nothing is packed
+    rt.aliasing, rt.numPasses = ANTIALIASING_ON, 2    # key 'a' / '2': flags only
+    check()
+    rt.maxDepth = 10                                  # key 'e'
+    check()
+    assert get_diagnostic("table_builds") == built
+    rt.rotateView(3.14 / 16, [0.0, 1.0, 0.0])         # key LEFT: the camera moves, the lights do not
+    check()
+    assert get_diagnostic("table_builds") == built + 1
+    rt.shapes[5].unif[0] += 1.0                       # a sphere moves: every table is rebuilt
+    check()
+    assert get_diagnostic("table_builds") == built + 1 + 5
+    rt.lights[1].loc[1] += 10.0                       # a light moves: its table only
+    check()
+    assert get_diagnostic("table_builds") == built + 1 + 5 + 1

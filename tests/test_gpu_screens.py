@@ -1,13 +1,11 @@
 """The conservative screens (single-precision per-sphere screen, two-level ball screen, per-family cone screens)
 must never change a result.  Random and adversarial sphere scenes, GPU against the CPU oracle, bit for bit, at
 every screen level (GRAFT_SCREEN = 0..4 caps the level a job may use; 0 is the plain double-precision loop)."""
-import os
-
 import numpy as np
 import pytest
 
 import oracle_binding as ob
-from raytracing_amd import scenes
+from raytracing_amd import get_diagnostic, scenes, set_diagnostic
 from raytracing_amd.tracer import (ANTIALIASING_OFF, ANTIALIASING_ON, GRAFT_OUT_F64_RGB, ORTHOGRAPHIC, PERSPECTIVE,
                                    Light, RayTracer, lightInit, lightSetAvoid)
 
@@ -37,19 +35,16 @@ def scene(seed, n, size=(64, 64), lights=3, radius=(5.0, 40.0), box=400.0, refl=
 
 def check_all_levels(rt, levels=(0, 1, 2, 3, 4)):
     want = ob.render(rt, threads=16, want_index=True)
-    old = os.environ.get("GRAFT_SCREEN")
+    old = get_diagnostic("screen_cap")
     try:
         for level in levels:
-            os.environ["GRAFT_SCREEN"] = str(level)
+            set_diagnostic("screen_cap", level)
             rgb, idx = rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_index=True)
             assert np.array_equal(idx, want["index"]), "index mask differs at screen level %d" % level
             assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64)), \
                 "RGB differs at screen level %d (max abs %g)" % (level, np.nanmax(np.abs(rgb - want["rgb"])))
     finally:
-        if old is None:
-            os.environ.pop("GRAFT_SCREEN", None)
-        else:
-            os.environ["GRAFT_SCREEN"] = old
+        set_diagnostic("screen_cap", old)
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -182,34 +177,27 @@ def test_groups_of_sixteen_and_other_sizes(gpu):
     """Scenes of 512+ spheres whose tables fit in LDS use 16 spheres per group; GRAFT_GROUP forces other sizes."""
     rt = large_scene(33, 600, lights=3, refl=0.4, depth=3)
     check_all_levels(rt, levels=(0, 2, 3))
-    old = os.environ.get("GRAFT_GROUP")
+    old = get_diagnostic("group_size")
     try:
-        for size in ("4", "12", "32"):
-            os.environ["GRAFT_GROUP"] = size
+        for size in (4, 12, 32):
+            set_diagnostic("group_size", size)
             check_all_levels(rt, levels=(2, 3))
             check_all_levels(large_scene(30, 1500, lights=5, refl=0.5, depth=3), levels=(4,))
     finally:
-        if old is None:
-            os.environ.pop("GRAFT_GROUP", None)
-        else:
-            os.environ["GRAFT_GROUP"] = old
+        set_diagnostic("group_size", old)
 
 
 def test_levels_are_actually_used(gpu):
     """The scenes above must really reach the screens they are meant to test."""
-    def level(rt, cap=None):
-        old = os.environ.pop("GRAFT_SCREEN", None)
+    def level(rt, cap=4):
+        old = set_diagnostic("screen_cap", cap)
         try:
-            if cap is not None:
-                os.environ["GRAFT_SCREEN"] = str(cap)
             job = rt.create_job()
             lv = job.screen_level()
             job.close()
             return lv
         finally:
-            os.environ.pop("GRAFT_SCREEN", None)
-            if old is not None:
-                os.environ["GRAFT_SCREEN"] = old
+            set_diagnostic("screen_cap", old)
     assert level(scene(0, 96)) == 3
     assert [level(scene(0, 96), cap) for cap in (0, 1, 2, 3)] == [0, 1, 2, 3]
     assert level(scenes.workload("cfg4", 64, 64)) == 3 and level(scenes.workload("cfg3", 64, 64)) == 3
