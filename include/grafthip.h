@@ -199,6 +199,24 @@ GRAFT_API int graftSynchronize(void);
 GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
                               void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost);
 
+/* graftRenderRows for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid it): no counterpart in the reference.  It calls no hipMalloc, hipFree, hipHostMalloc or other
+ * allocating HIP routine: the device block a trace reads (tables + ticket counters) lives in a static __device__
+ * array of GRAFT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends, reached
+ * through the address graftInit looked up for that GPU, and the upload goes through a page-locked block graftInit
+ * allocated.  (Packing the scene on the host uses the C++ heap, as graftJobCreate does.)  Inputs are host structs as
+ * for graftRenderRows; outputs are DEVICE buffers of the caller: `frameDevice` nRows*nCols pixels of `format`,
+ * `hitIndexDevice` and `countersDevice` optional as for graftJobTrace (counters are ADDED to).  Asynchronous on
+ * `stream` (NULL = the library's stream).  A scene + view that packs to more than the scratch block is refused with
+ * GRAFT_ERR_UNSUPPORTED (4096 spheres with 4 lights at 16384 x 16384 pack to 1.2 MB).  Every call on a GPU uses that
+ * GPU's one block, which keeps the previous call's contents until the next upload: calls on one stream follow each
+ * other safely; calls of this entry point that overlap in time on one GPU (different streams) race.  One-sample-per-pixel traces never park mirror rays here (that needs queue
+ * memory), so a frame may take longer than through graftJobTrace; results are identical. */
+#define GRAFT_NOALLOC_SCRATCH_BYTES (4u << 20)
+GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
+                                     void *frameDevice, int32_t *hitIndexDevice, GraftCounters *countersDevice,
+                                     void *stream);
+
 /* Write a host frame (row iy = 0 is the BOTTOM row, as pixSetRGB's y: 000pixel.h:53-55) as a binary PPM (P6, top
  * row first), quantising with q(v) = (uint8)(min(max(v,0),1)*255 + 0.5) where the format is not already 8 bit.
  * For headless runs: the reference can only show its frame in a window (000pixel.h:31-39). */

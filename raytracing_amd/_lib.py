@@ -84,6 +84,9 @@ lib.graftJobTrace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctype
 lib.graftSynchronize.restype = ctypes.c_int
 lib.graftRenderRows.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTER(GraftView), ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+lib.graftRenderRowsNoAlloc.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTER(GraftView), ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p]
 lib.graftWritePPM.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 lib.graftDiagnosticSet.argtypes = [ctypes.c_int, ctypes.c_int]
 lib.graftDiagnosticGet.argtypes = [ctypes.c_int]

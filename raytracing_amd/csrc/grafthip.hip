@@ -31,6 +31,12 @@
 
 using namespace graft;
 
+// Device memory of the entry point that allocates nothing (graftRenderRowsNoAlloc): every GPU the library runs on
+// holds one copy of this array, at an address of its own, until the process ends.  Host code never uses the name
+// as an address: graftInit asks the runtime for the array's device address (hipGetSymbolAddress, with that device
+// current) and keeps it in Device::scratch.
+static __device__ __align__(256) unsigned char scratch[(size_t)4 << 20];
+
 namespace {
 
 // SCREEN: 0 = exact double loop, 1 = single-precision screen per sphere, 2 = two-level ball screen,
@@ -507,6 +513,7 @@ struct Reusable {
 };
 
 constexpr int kMaxDevices = 16;
+constexpr size_t kScratchBytes = (size_t)4 << 20;  // device block of graftRenderRowsNoAlloc: tables + ticket counters
 
 // What the library holds per GPU.
 struct Device {
@@ -518,6 +525,11 @@ struct Device {
     std::vector<unsigned char> cacheKey;  // the input that job was packed from
     GraftJob *cacheJob = nullptr;
     std::vector<const void *> configured;  // kernels whose dynamic-LDS limit has been raised on this device
+    // graftRenderRowsNoAlloc: this device's copy of `scratch`, a page-locked staging block of the same size and the
+    // event that says the last upload from it has finished (all three set up by graftInit, never per call)
+    unsigned char *scratch = nullptr;
+    unsigned char *scratchStage = nullptr;
+    hipEvent_t scratchCopied = nullptr;
 };
 
 Device gDevices[kMaxDevices];
@@ -615,6 +627,10 @@ int initDevice(int device, Device **out) {
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         D.numCU = prop.multiProcessorCount;
         HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+        static_assert(sizeof(scratch) == kScratchBytes, "scratch size");
+        HIP_TRY(hipGetSymbolAddress((void **)&D.scratch, HIP_SYMBOL(scratch)));  // this device's copy of the array
+        HIP_TRY(hipHostMalloc((void **)&D.scratchStage, kScratchBytes, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&D.scratchCopied, hipEventDisableTiming));
         D.id = device;
         D.ready = true;
     }
@@ -629,6 +645,11 @@ void releaseDevice(Device &D) {
         (void)hipStreamSynchronize(D.stream);
         (void)hipStreamDestroy(D.stream);
     }
+    if (D.scratchCopied) (void)hipEventDestroy(D.scratchCopied);
+    if (D.scratchStage) (void)hipHostFree(D.scratchStage);
+    D.scratchCopied = nullptr;
+    D.scratchStage = nullptr;
+    D.scratch = nullptr;
     delete D.cacheJob;
     D.cacheJob = nullptr;
     D.cacheKey.clear();
@@ -953,6 +974,32 @@ GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, in
     if (rc == GRAFT_OK && dCnt && (e = hipMemcpyAsync(countersHost, dCnt, sizeof(GraftCounters), hipMemcpyDeviceToHost, D->stream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(counters): %s", hipGetErrorString(e));
     if ((e = hipStreamSynchronize(D->stream)) != hipSuccess && rc == GRAFT_OK) rc = fail(GRAFT_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
     return rc;
+}
+
+GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
+                                     void *frameDevice, int32_t *hitIndexDevice, GraftCounters *countersDevice,
+                                     void *stream) {
+    if (!gBound) return fail(GRAFT_ERR_STATE, "graftRenderRowsNoAlloc: call graftInit first");
+    Device *D = gBound;
+    PackedJob J;
+    std::string err;
+    int rc = packJob(scene, view, gSettings, gTables, J, err);
+    if (rc != GRAFT_OK) return fail(rc, "graftRenderRowsNoAlloc: %s", err.c_str());
+    if (J.image.size() > kScratchBytes)
+        return fail(GRAFT_ERR_UNSUPPORTED, "graftRenderRowsNoAlloc: scene and view pack to %zu bytes, the static "
+                    "scratch block holds %zu (use graftRenderRows or graftJobCreate)", J.image.size(), kScratchBytes);
+    GraftJob job;
+    describe(&job, J, D->scratch, false, D);
+    rc = checkTraceArgs("graftRenderRowsNoAlloc", &job, row0, nRows, format, frameDevice);
+    if (rc != GRAFT_OK) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : D->stream;
+    // the staging block may still be the source of the previous call's upload
+    HIP_TRY(hipEventSynchronize(D->scratchCopied));
+    memcpy(D->scratchStage, J.image.data(), J.image.size());
+    HIP_TRY(hipMemcpyAsync(D->scratch, D->scratchStage, J.image.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(D->scratchCopied, s));
+    // (the ticket counters inside the block are set by the launch itself, behind the upload on the same stream)
+    return launchTrace(&job, row0, nRows, format, frameDevice, hitIndexDevice, countersDevice, s);
 }
 
 static int probe(int which, const double *a, const double *b, double *out, size_t n) {

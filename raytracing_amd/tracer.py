@@ -439,6 +439,17 @@ class RayTracer:
             self.last_counters = (counters.rays, counters.tests)
         return (frame, index) if want_index else frame
 
+    def render_rows_no_alloc(self, row0, n_rows, fmt, frame_ptr, index_ptr=None, counters_ptr=None, stream=None):
+        """graftRenderRowsNoAlloc: trace loop rows [row0,row0+n_rows) into DEVICE buffers of the caller without any
+        device allocation (asynchronous on `stream`, None = the library's stream: lib.graftSynchronize() waits)."""
+        init(_bound_device if _bound_device is not None else 0)
+        self.camInitialize(self.target, self.targetToScreen, self.screenToCam)
+        scene, view, keep = self.pack()
+        check(lib.graftRenderRowsNoAlloc(ctypes.byref(scene), ctypes.byref(view), int(row0), int(n_rows), int(fmt),
+                                         ctypes.c_void_p(frame_ptr), ctypes.c_void_p(index_ptr or 0),
+                                         ctypes.c_void_p(counters_ptr or 0), ctypes.c_void_p(stream or 0)))
+        del keep
+
     def launchRays(self, pixSetRGB=None):
         """mainTracing.c:387-443.  Traces the whole frame on the GPU, then replays the reference's pixSetRGB
         calls (x outer, y inner, :392-393, :439) into self.frame[y][x] -- and into `pixSetRGB(x, y, r, g, b)`
