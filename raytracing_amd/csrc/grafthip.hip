@@ -50,7 +50,15 @@ namespace {
 // per-lane stack holds a tree walk (wider entries) instead of a chain.
 // MANYCURSORS: tickets come from kCursors counters instead of one (launches of cheap tiles, see below).  A
 // separate instantiation because the expensive-tile kernels lose 1-3 % to any change of this code (measured).
-template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS>
+// PARK (one sample per pixel, mirror shapes, no transparency; MANYCURSORS kernels only): a pixel whose primary hit
+// reflects is not followed down its mirror chain by the lane that found it.  After the tile's primary and shadow
+// rays the lane writes the mirror ray and the level's partial sum into the wave's own queue in global memory and
+// the wave moves on to its next tile; as soon as 64 pixels are queued the wave takes them back, one per lane, and
+// traces their chains with every lane busy (reflect() rays leave a tile in all directions, and only some pixels
+// of a tile have one: traced in place they keep a quarter of the lanes busy).  The value of a pixel does not
+// depend on which lane finishes it, and with one sample per pixel there is no sum over samples whose order could
+// change.  Only the wave that wrote a queue entry reads it, so no ordering between waves is involved.
+template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS, bool PARK = false>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
     if (LDSGEOM) {
         if (SCREEN == 4) {
@@ -112,9 +120,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         }
         return avoided;
     };
-    // one finished pixel: column ix, row `by` of the band
-    auto storePixel = [&](int ix, int by, const double acc[3], int firstIdx) {
-        const size_t p = (size_t)by * P.nCols + ix;
+    // one finished pixel: number p of the band (row-major)
+    auto storeColor = [&](size_t p, const double acc[3]) {
         if (P.format == GRAFT_OUT_F64_RGB) {
             double *f = (double *)P.frame + 3 * p;
             f[0] = acc[0]; f[1] = acc[1]; f[2] = acc[2];
@@ -125,7 +132,6 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             unsigned w = quant8(acc[0]) | (quant8(acc[1]) << 8) | (quant8(acc[2]) << 16) | 0xff000000u;
             ((unsigned *)P.frame)[p] = w;
         }
-        if (P.hitIndex) P.hitIndex[p] = firstIdx;
     };
 
     // Tiles are handed out in tickets of `tilesPerTicket` consecutive tiles drawn from shared counters.  One address
@@ -143,8 +149,20 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     int usedUp = 0;  // counters found empty so far (wave-uniform)
     if (MANYCURSORS && P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
     int tile = 0, tileEnd = 0;
+    // PARK: the wave's queue of parked pixels.  Field f of slot i is the 8-byte word f * kParkSlots + i; fields 0-2
+    // origin and 3-5 direction of the mirror ray, 6-8 the level's partial sum, 9 = {shape hit, pixel of the band}.
+    // A tile adds at most 64 entries and the wave empties 64 whenever it holds that many, so slots stay below 128.
+    unsigned long long *const queue =
+        PARK ? P.parkQueue + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (kParkFields * kParkSlots) : nullptr;
+    int queued = 0;        // entries in the queue (wave-uniform)
+    bool tilesLeft = true;
     for (;;) {
-        if (tile >= tileEnd) {
+        int resumed = 0;  // PARK: lanes that take a parked pixel in this round instead of a tile's
+        if (PARK) {
+            if (queued >= 64 || (!tilesLeft && queued > 0)) resumed = queued < 64 ? queued : 64;
+            else if (!tilesLeft) break;  // every wave gets here: its tickets run out and its queue drains
+        }
+        if (resumed == 0 && tile >= tileEnd) {
             if (MANYCURSORS) {
                 const int numTickets = (P.numTiles + P.tilesPerTicket - 1) / P.tilesPerTicket;
                 if (!P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
@@ -154,14 +172,23 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     if (lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
                     ticket = __builtin_amdgcn_readfirstlane(nextTicket) * kCursors + cursor;
                 }
-                if (ticket >= numTickets) break;  // every wave gets here: the counters only grow
+                if (ticket >= numTickets) {  // every wave gets here: the counters only grow
+                    if (!PARK) break;
+                    tilesLeft = false;
+                    continue;
+                }
                 tile = ticket * P.tilesPerTicket;
                 tileEnd = min(tile + P.tilesPerTicket, P.numTiles);
                 if (P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
             } else {
                 const int ticket = __builtin_amdgcn_readfirstlane(nextTicket);
                 tile = ticket * P.tilesPerTicket;
-                if (tile >= P.numTiles) break;  // every wave reaches this: the counter only grows
+                if (tile >= P.numTiles) {  // every wave reaches this: the counter only grows
+                    if (!PARK) break;
+                    tilesLeft = false;
+                    tile = tileEnd = 0;
+                    continue;
+                }
                 tileEnd = min(tile + P.tilesPerTicket, P.numTiles);
                 if (lane == 0) nextTicket = atomicAdd(P.tileCursor, 1);
             }
@@ -170,13 +197,18 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         const int ix = tx * kTile + lx;
         const int by = ty * kTile + ly;  // row inside the band
         const int iy = P.row0 + by;
-        const bool inside = ix < P.nCols && by < P.bandRows;
+        const bool inside = PARK && resumed ? lane < resumed : ix < P.nCols && by < P.bandRows;
+        // entries are read back by other lanes of the wave than those that stored them: the stores complete first
+        if (PARK && resumed) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        bool parkMe = false;  // PARK: this lane's pixel goes into the queue at the end of the round
 
         const ConstDoubles cam = cameraView(P);
         double acc[3] = {cam[CAM_BACKGROUND], cam[CAM_BACKGROUND + 1], cam[CAM_BACKGROUND + 2]};  // mainTracing.c:395
         int firstIdx = -1;
         if (inside) {
-            const double colI = P.colOff[ix], rowJ = P.rowOff[iy];
+            double colI = 0, rowJ = 0;
+            if (!(PARK && resumed)) { colI = P.colOff[ix]; rowJ = P.rowOff[iy]; }
+            size_t pixel = (size_t)by * P.nCols + ix;
             // per-lane machine state
             int mode, depth = 0, sample = 0, li = 0, sp = 0, hitIdx = -1, litLight = -1;
             double o[3], d[3];                 // current ray
@@ -215,7 +247,28 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             // maxDepth <= 0: shootRay returns black before it looks at the scene (mainTracing.c:302-306), for every
             // sample; with anti-aliasing the background-seeded sum (:395) takes n additions of zero
             const bool traceNothing = P.maxDepth <= 0;
-            if (P.hitIndex && (P.aliasing || traceNothing)) {  // mask ray = the anti-aliasing-off ray of this pixel
+            if (PARK && resumed) {  // take a parked pixel back: its primary hit's level is entry 0 of the stack again
+                // (loads that go to the L2: the entry was stored by this wave, possibly through another lane)
+                unsigned long long *q = queue + (queued - resumed + lane);
+                auto word = [&](int f) { return __hip_atomic_load(q + f * kParkSlots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                for (int c = 0; c < 3; ++c) {
+                    o[c] = __longlong_as_double((long long)word(c));
+                    d[c] = __longlong_as_double((long long)word(3 + c));
+                    stk[c] = __longlong_as_double((long long)word(6 + c));
+                }
+                const unsigned long long tag = word(9);
+                pixel = (size_t)(tag >> 32);
+                const DevMaterial &m = P.materials[(int)(tag & 0xffffffffu)];
+                for (int c = 0; c < 3; ++c) {
+                    const double t = (1 - .5) * (1.0 - m.color[c]);  // mainTracing.c:334-336
+                    stk[3 + c] = m.color[c] + t;
+                }
+                stk[6] = (1 - m.ambientLight) * m.reflectivity;  // mainTracing.c:359
+                flags[0] = F_MIRROR_PENDING;
+                sp = 1;
+                depth = 1;
+                mode = M_RADIANCE;
+            } else if (P.hitIndex && (P.aliasing || traceNothing)) {  // mask ray = the anti-aliasing-off ray of this pixel
                 primaryRay(P, colI, rowJ, o, d);
                 mode = M_INDEX;
             } else if (traceNothing) {
@@ -354,6 +407,10 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                                 depth++;
                                 rayReflects = 1;  // reflection() passes shouldReflect = 1, :181
                                 mode = M_RADIANCE;
+                                if (PARK && depth == 1) {  // the primary hit's mirror ray: queue it, trace it later
+                                    parkMe = true;
+                                    mode = M_DONE;
+                                }
                             }
                         } else {  // glass without a mirror ray: reflectionRGB stays {0,0,0}; go straight to refraction
                             for (int c = 0; c < 3; ++c) lv[c] = (wRefl * 0.0) + part[c];
@@ -433,9 +490,31 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 const double n = (double)nSamples;
                 acc[0] = acc[0] / n; acc[1] = acc[1] / n; acc[2] = acc[2] / n;
             }
-            storePixel(ix, by, acc, firstIdx);
+            if (!(PARK && resumed) && P.hitIndex) P.hitIndex[pixel] = firstIdx;
+            if (PARK && parkMe) {
+                const unsigned long long mine = __ballot(1) & __ballot(parkMe);
+                const int slot = queued + __popcll(mine & ((1ull << lane) - 1));
+                unsigned long long *q = queue + slot;
+                for (int c = 0; c < 3; ++c) {
+                    q[c * kParkSlots] = (unsigned long long)__double_as_longlong(o[c]);
+                    q[(3 + c) * kParkSlots] = (unsigned long long)__double_as_longlong(d[c]);
+                    q[(6 + c) * kParkSlots] = (unsigned long long)__double_as_longlong(stk[c]);
+                }
+                q[9 * kParkSlots] = ((unsigned long long)pixel << 32) | (unsigned)hitIdx;
+            } else {
+                storeColor(pixel, acc);
+            }
         }
-        ++tile;
+        if (PARK) {
+            if (resumed) {
+                queued -= resumed;
+            } else {
+                queued += __popcll(__ballot(parkMe));
+                ++tile;
+            }
+        } else {
+            ++tile;
+        }
     }
     if (P.counters) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -522,6 +601,7 @@ struct Device {
     hipStream_t stream = nullptr;
     Reusable frame, index, counters;      // device side of graftRenderRows' host buffers
     Reusable arena;                       // device block of the job graftRenderRows keeps between calls
+    Reusable parkQueue;                   // queues of parked pixels, one per wave of the largest PARK launch so far
     std::vector<unsigned char> cacheKey;  // the input that job was packed from
     GraftJob *cacheJob = nullptr;
     std::vector<const void *> configured;  // kernels whose dynamic-LDS limit has been raised on this device
@@ -552,6 +632,14 @@ void readSettingsOnce() {
 
 typedef void (*TraceFn)(const TraceParams);
 
+// PARK kernels: many-counter launches of sphere-only scenes whose tables sit in LDS (screen levels 2 to 4)
+template <int A>
+TraceFn pickKernelPark(int screen, bool exactLds) {
+    if (screen == 2) return exactLds ? traceKernel<A, true, 2, true, false, true, true> : traceKernel<A, true, 2, false, false, true, true>;
+    if (screen == 3) return exactLds ? traceKernel<A, true, 3, true, false, true, true> : traceKernel<A, true, 3, false, false, true, true>;
+    return traceKernel<A, true, 4, false, false, true, true>;
+}
+
 template <int A, bool M>
 TraceFn pickKernelA(bool lds, int screen, bool exactLds) {
     if (!lds) return screen == 2 ? traceKernel<A, false, 2, false, false, M> : screen == 1 ? traceKernel<A, false, 1, false, false, M> : traceKernel<A, false, 0, false, false, M>;
@@ -574,7 +662,9 @@ TraceFn pickKernelM(int avoidMode, bool lds, int screen, bool exactLds, bool tra
          : avoidMode == 1 ? pickKernelA<1, M>(lds, screen, exactLds) : pickKernelA<2, M>(lds, screen, exactLds);
 }
 
-TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool manyCursors) {
+TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool manyCursors, bool park) {
+    if (park) return avoidMode == 0 ? pickKernelPark<0>(screen, exactLds)
+                   : avoidMode == 1 ? pickKernelPark<1>(screen, exactLds) : pickKernelPark<2>(screen, exactLds);
     return manyCursors ? pickKernelM<true>(avoidMode, lds, screen, exactLds, transp)
                        : pickKernelM<false>(avoidMode, lds, screen, exactLds, transp);
 }
@@ -591,7 +681,8 @@ struct GraftJob {
     bool mirrors;   // some shape reflects
     size_t ldsBytes;
     int block;
-    int blocksPerCU;  // resident workgroups per CU (occupancy query at the first trace), 0 = not asked yet
+    int blocksPerCU;  // resident workgroups per CU of kernel `occupancyOf` (asked when a trace first uses a kernel)
+    const void *occupancyOf;
     void *arena;      // the device block holding every table
     bool ownsArena;   // false: the block belongs to a Device (graftRenderRows' cached job)
     Device *dev;
@@ -610,6 +701,7 @@ void describe(GraftJob *job, const PackedJob &J, void *base, bool owns, Device *
     job->ldsBytes = J.ldsBytes;
     job->block = J.block;
     job->blocksPerCU = 0;
+    job->occupancyOf = nullptr;
     job->arena = base;
     job->ownsArena = owns;
     job->dev = dev;
@@ -657,6 +749,7 @@ void releaseDevice(Device &D) {
     D.index.release();
     D.counters.release();
     D.arena.release();
+    D.parkQueue.release();
     D.configured.clear();
     D.stream = nullptr;
     D.ready = false;
@@ -664,7 +757,7 @@ void releaseDevice(Device &D) {
 
 // Queue one trace of rows [row0, row0 + nRows) of `job` on stream `s` of the job's device (which must be current).
 int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int32_t *hitIndex, GraftCounters *counters,
-                hipStream_t s) {
+                hipStream_t s, bool mayAllocate = true) {
     Device *D = job->dev;
     TraceParams P = job->P;
     P.row0 = row0; P.bandRows = nRows; P.format = format;
@@ -677,16 +770,21 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     // cheap tiles (few samples per pixel) are drawn several at a time and from several counters
     const int samples = P.aliasing ? P.numPasses * P.numPasses : 1;
     const bool manyCursors = samples < 4;
-    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, manyCursors);
+    // one sample per pixel, mirrors, at least one bounce: the primary hits' mirror rays are parked and traced in full
+    // waves (needs queue memory: not on the path that must not allocate)
+    const bool park = gSettings.park && mayAllocate && samples == 1 && job->mirrors && !job->transp && P.maxDepth >= 2 &&
+                      job->lds && job->screen >= 2 && tiles * 64 < 0xffffffffLL;
+    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, manyCursors, park);
     if (job->lds && std::find(D->configured.begin(), D->configured.end(), (const void *)fn) == D->configured.end()) {
         // more dynamic LDS than the default limit: raised once per kernel and device, when the kernel is first used
         HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
         D->configured.push_back((const void *)fn);
     }
-    if (job->blocksPerCU == 0) {  // persistent grid: as many workgroups as the kernel's registers and LDS let a CU hold
+    if (job->occupancyOf != (const void *)fn) {  // persistent grid: as many workgroups as the kernel's registers and LDS let a CU hold
         int perCU = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)fn, job->block, job->ldsBytes));
         job->blocksPerCU = perCU < 1 ? 1 : perCU;
+        job->occupancyOf = (const void *)fn;
     }
     const int blocksPerCU = job->blocksPerCU;
     long long wantBlocks = (tiles + wavesPerBlock - 1) / wavesPerBlock;
@@ -700,6 +798,14 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     if (gSettings.tilesPerTicket > 0) perTicket = gSettings.tilesPerTicket;  // diagnostics: forced ticket size
     P.tilesPerTicket = (int)perTicket;
     P.prefetchTickets = (tiles + perTicket - 1) / perTicket >= 8 * waves ? 1 : 0;
+    if (park) {
+        // One queue per wave.  Growing the buffer frees the old one, which an earlier launch may still be using.
+        const size_t need = (size_t)waves * kParkFields * kParkSlots * sizeof(unsigned long long);
+        if (need > D->parkQueue.cap) HIP_TRY(hipDeviceSynchronize());
+        hipError_t e = D->parkQueue.reserve(need);
+        if (e != hipSuccess) return fail(GRAFT_ERR_HIP, "hipMalloc(park queues, %zu): %s", need, hipGetErrorString(e));
+        P.parkQueue = (unsigned long long *)D->parkQueue.ptr;
+    }
     if (manyCursors) HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int) * kCursors * kCursorStride, s));
     else HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)P.tileCursor, grid * wavesPerBlock, 1, s));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(job->block), job->ldsBytes, s, P);
@@ -999,7 +1105,7 @@ GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *v
     HIP_TRY(hipMemcpyAsync(D->scratch, D->scratchStage, J.image.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(D->scratchCopied, s));
     // (the ticket counters inside the block are set by the launch itself, behind the upload on the same stream)
-    return launchTrace(&job, row0, nRows, format, frameDevice, hitIndexDevice, countersDevice, s);
+    return launchTrace(&job, row0, nRows, format, frameDevice, hitIndexDevice, countersDevice, s, false);
 }
 
 static int probe(int which, const double *a, const double *b, double *out, size_t n) {
