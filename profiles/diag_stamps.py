@@ -13,7 +13,7 @@ raytracing_amd.init(0)
 rt = scenes.workload(name, None, height)
 job = rt.create_job()
 frame = torch.empty((job.nRows, job.nCols, 4), dtype=torch.float32, device="cuda")
-cnt = torch.zeros(12, dtype=torch.int64, device="cuda")
+cnt = torch.zeros(16, dtype=torch.int64, device="cuda")
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 for _ in range(2):
     cnt.zero_()
@@ -30,3 +30,7 @@ print("%s: waves %d, tiles %d, wave-rounds %d (%.1f lanes busy per round), cycle
          (total - loop) / tiles))
 print("   per wave-round: %.1f third-level entries opened, %.1f groups whose members were screened, %.1f exact sphere tests"
       % (c[9] / max(rounds, 1), c[7] / max(rounds, 1), c[8] / max(rounds, 1)))
+if c[12]:
+    print("   grid walk: %d calls (%.1f lanes each), %.1f loop iterations per call with %.1f lanes alive on average, "
+          "%.0f cycles per call (%.1f%% of wave time), %.1f cycles per iteration"
+          % (c[12], c[13] / c[12], c[10] / c[12], c[11] / max(c[10], 1), c[14] / c[12], 100.0 * c[14] / total, c[14] / max(c[10], 1)))

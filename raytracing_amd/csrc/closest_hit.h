@@ -436,7 +436,7 @@ __device__ __forceinline__ void coneBlock(const float4v c0, const float4v c1, co
 // argument for skipping is the same as for a group: the entry encloses every member with the member's own margin.
 // (With lanes of one wave following different families the groups to open add up, which is why smaller scenes,
 // whose tables fit in LDS whole, keep the two-level walk: measured 34 vs 23 Grays/s on 1024 spheres.)
-template <int AVOID, bool EXACTLDS, bool SUPER>
+template <int AVOID, bool EXACTLDS, bool SUPER, bool BALL = true>
 __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double sx, double sy, double sz, double dx,
                                                    double dy, double dz, int avoidShape, const unsigned char *avoidRow,
                                                    int family, float negThreshold, Hit &h) {
@@ -617,8 +617,175 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
             flush();
         }
     };
-    if (family != P.ballFamily) walk(std::true_type{});
-    else walk(std::false_type{});
+    if (!BALL || family != P.ballFamily) walk(std::true_type{});
+    else if (BALL) walk(std::false_type{});
+    finishBest(closest, sx, sy, sz, dx, dy, dz, h);
+}
+
+// Closest hit for rays that pass through no fixed point -- mirror rays and the shadow rays of what they hit -- in
+// scenes whose per-family tables carry a uniform grid (packGrid).  Such rays leave a tile in all directions: a walk
+// in which all lanes of a wave look at the same table entry costs the union of what the lanes need, so here every
+// lane walks ITS OWN cells front to back (3-D DDA) and tests its own cells' spheres; the instructions are shared,
+// the addresses are not.  Per sphere the single-precision screen of closestHitScreened (same arithmetic, same error
+// budget) decides whether the exact test runs; exact tests are deferred one deep (`pending`) so that the expensive
+// code runs when some lane needs the slot again, for all lanes that have a candidate.
+//
+// What makes it exact: a sphere the ray hits at parameter t has its hit point s + t d on its surface (to rounding),
+// hence inside a cell that lists it, and every point within kGroupMargin of that cell's box lies in a cell that lists
+// it as well.  The walk's idea of where the ray is differs from the true line by rounding only (double precision:
+// ~1e-9 of the margin), so among the cells it visits up to parameter t there is one that lists the sphere.  A lane
+// stops when its best hit lies before the exit of the cell just finished by more than `slack` (no unvisited cell can
+// hold a closer or equally close hit), or when it leaves the grid (every sphere lies inside).
+//
+// tLimit < infinity marks a shadow ray towards a light at that parameter.  The caller only asks whether the closest
+// hit lies before or beyond the light (mainTracing.c:211-215: lit iff no hit, or the vector from the hit to the light
+// points backwards).  Any hit that is before the light by more than 1e-6 (relative and absolute) settles "before"
+// whichever sphere is closest, and nothing that starts beyond the light by that much can change "beyond"; only when
+// the best hit falls inside that band is the walk continued to the exact closest hit, which the caller then judges
+// with the reference's own arithmetic.
+template <int AVOID>
+__device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, double sy, double sz, double dx, double dy,
+                                               double dz, int avoidShape, const unsigned char *avoidRow,
+                                               float negThreshold, double tLimit, Hit &h) {
+    const ConstDoubles G = (ConstDoubles)(unsigned long long)P.grid;
+    const unsigned *cells = (const unsigned *)((const char *)ldsGeom + P.gridCellsOff);
+    const unsigned short *refs = (const unsigned short *)((const char *)ldsGeom + P.gridRefsOff);
+    const float4v *aos = (const float4v *)((const char *)ldsGeom + P.gridAosOff);
+    const double *geom = P.geom;
+    Best closest = {0, -1, -1};
+    const double slackBase = fabs(sx) + fabs(sy) + fabs(sz);
+    const double dd = dx * dx + dy * dy + dz * dz;
+    const double slackScale = dd > 0.99 && dd < 1.01 ? 2e-15 : INFINITY;
+    const float sxf = (float)sx, syf = (float)sy, szf = (float)sz;
+    const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
+    const int nx = P.gridNx, ny = P.gridNy, nz = P.gridNz;
+
+    // the part of the ray inside the grid's box, and per axis: step, parameter of the next cell face, parameter per cell
+    double tEnter = 0, tLeave = INFINITY;
+    bool alive = true;
+    double tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ, invX = 0, invY = 0, invZ = 0;
+    auto slab = [&](double o, double d, double lo, double hi, double &inv) {
+        if (fabs(d) > 1e-150) {  // (a smaller component moves the ray by nothing over any distance in the grid)
+            double r = __builtin_amdgcn_rcp(d);
+            r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+            inv = r;
+            const double t0 = (lo - o) * r, t1 = (hi - o) * r;
+            tEnter = fmax(tEnter, fmin(t0, t1));
+            tLeave = fmin(tLeave, fmax(t0, t1));
+        } else if (o < lo || o > hi) {
+            alive = false;
+        }
+    };
+    slab(sx, dx, G[GRID_LO], G[GRID_HI], invX);
+    slab(sy, dy, G[GRID_LO + 1], G[GRID_HI + 1], invY);
+    slab(sz, dz, G[GRID_LO + 2], G[GRID_HI + 2], invZ);
+    alive = alive && tEnter <= tLeave;
+    int cx = 0, cy = 0, cz = 0, stepX = 0, stepY = 0, stepZ = 0;
+    auto enter = [&](double o, double d, double inv, double lo, double cs, double invCs, int n, int &c, int &step,
+                     double &tMax, double &tDelta) {
+        const double p = o + tEnter * d;
+        double f = floor((p - lo) * invCs);
+        f = f < 0 ? 0 : (f > (double)(n - 1) ? (double)(n - 1) : f);  // (false for NaN: cell 0)
+        c = (int)f;
+        if (inv != 0) {
+            step = d > 0 ? 1 : -1;
+            const double face = lo + (f + (d > 0 ? 1.0 : 0.0)) * cs;
+            tMax = (face - o) * inv;
+            tDelta = cs * fabs(inv);
+        } else {
+            step = 0;
+            tMax = INFINITY;
+            tDelta = 0;
+        }
+    };
+    enter(sx, dx, invX, G[GRID_LO], G[GRID_CS], G[GRID_INVCS], nx, cx, stepX, tMaxX, tDeltaX);
+    enter(sy, dy, invY, G[GRID_LO + 1], G[GRID_CS + 1], G[GRID_INVCS + 1], ny, cy, stepY, tMaxY, tDeltaY);
+    enter(sz, dz, invZ, G[GRID_LO + 2], G[GRID_CS + 2], G[GRID_INVCS + 2], nz, cz, stepZ, tMaxZ, tDeltaZ);
+
+    const bool shadow = tLimit < INFINITY;
+    const double tSure = tLimit * (1 - 1e-6) - 1e-6, tStop = tLimit * (1 + 1e-6) + 1e-6;
+    int ref = 0, refEnd = 0, pending = -1, last = -1;
+    auto openCell = [&]() {
+        const unsigned r = cells[(cz * ny + cy) * nx + cx];
+        ref = (int)(r >> 8);
+        refEnd = ref + (int)(r & 255u);
+    };
+    auto flush = [&]() {
+#ifdef GRAFT_STAMPS
+        if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
+#endif
+        if (pending >= 0) {
+            exactSphereLazy(geom, pending, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
+            pending = -1;
+        }
+    };
+    if (alive) openCell();
+#ifdef GRAFT_STAMPS  // diagnostic build: calls, iterations of the loop below, lanes alive in them, rounds of exact tests
+    const bool stampLeader = lane64() == (int)__builtin_ctzll(__ballot(1));
+    if (P.counters && stampLeader) { atomicAdd(P.counters + 12, 1ull); atomicAdd(P.counters + 13, (unsigned long long)__popcll(__ballot(1))); }
+    const unsigned long long stampGrid0 = clock64();
+#endif
+    while (alive) {
+#ifdef GRAFT_STAMPS
+        if (P.counters) {
+            const unsigned long long on = __ballot(1);
+            if (lane64() == (int)__builtin_ctzll(on)) { atomicAdd(P.counters + 10, 1ull); atomicAdd(P.counters + 11, (unsigned long long)__popcll(on)); }
+        }
+#endif
+        // up to two entries of the lane's cell through the screen
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            int cand = -1;
+            if (ref < refEnd) {
+                const int k = refs[ref++];
+                if (k != last) {  // (a sphere that straddles two cells is listed in both, next to each other in time)
+                    last = k;
+                    const float4v e = aos[k];
+                    const float vx = sxf - e.x, vy = syf - e.y, vz = szf - e.z;
+                    float b = vx * dxf;
+                    b = __builtin_fmaf(vy, dyf, b);
+                    b = __builtin_fmaf(vz, dzf, b);
+                    float vv = vx * vx;
+                    vv = __builtin_fmaf(vy, vy, vv);
+                    vv = __builtin_fmaf(vz, vz, vv);
+                    const float val = __builtin_fmaf(b, b, e.w - vv);
+                    bool take = !(val < negThreshold);
+                    if (AVOID == 1) take = take && k != avoidShape;
+                    if (AVOID == 2) take = take && !(avoidRow && avoidRow[k]);
+                    if (take) cand = k;
+                }
+            }
+            if (__ballot(cand >= 0 && pending >= 0)) flush();
+            if (cand >= 0) pending = cand;
+        }
+        const bool cellDone = ref >= refEnd;
+        if (__ballot(cellDone && pending >= 0)) flush();
+        if (cellDone) {
+            const double tExit = fmin(tMaxX, fmin(tMaxY, tMaxZ));
+            bool stop = tExit > tStop;  // (shadow rays only: tStop is infinite otherwise)
+            if (closest.shape >= 0) {
+                stop = stop || closest.t < tExit - (1e-7 * (fabs(tExit) + slackBase) + 1e-9);
+                stop = stop || (shadow && closest.t < tSure);
+            }
+            if (!stop) {
+                if (tMaxX <= tMaxY && tMaxX <= tMaxZ) {
+                    cx += stepX; tMaxX += tDeltaX;
+                    stop = cx < 0 || cx >= nx;
+                } else if (tMaxY <= tMaxZ) {
+                    cy += stepY; tMaxY += tDeltaY;
+                    stop = cy < 0 || cy >= ny;
+                } else {
+                    cz += stepZ; tMaxZ += tDeltaZ;
+                    stop = cz < 0 || cz >= nz || stepZ == 0;  // (all three parameters infinite: a ray that does not move)
+                }
+            }
+            if (stop) alive = false;
+            else openCell();
+        }
+    }
+#ifdef GRAFT_STAMPS
+    if (P.counters && stampLeader) atomicAdd(P.counters + 14, (unsigned long long)(clock64() - stampGrid0));
+#endif
     finishBest(closest, sx, sy, sz, dx, dy, dz, h);
 }
 

@@ -42,7 +42,8 @@ namespace {
 // SCREEN: 0 = exact double loop, 1 = single-precision screen per sphere, 2 = two-level ball screen,
 // 3 = two-level screens per ray family (cones for primary and shadow rays, balls for the rest; LDS only),
 // 4 = large scenes: three-level screens per ray family (an entry per 8 groups on top), the cone families' member
-//     sections left in global memory.
+//     sections left in global memory;
+// 5 = level 4 with a uniform grid walked lane by lane in place of the ball family (closestHitGrid).
 // LDSGEOM: the table the hot loop reads (screen table, or the doubles when SCREEN == 0) is staged in LDS.
 // EXACTLDS (SCREEN > 0 only): the exact doubles are staged in LDS as well, behind the screen table; otherwise the
 // rare exact tests read them from global memory.
@@ -61,7 +62,7 @@ namespace {
 template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS, bool PARK = false>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
     if (LDSGEOM) {
-        if (SCREEN == 4) {
+        if (SCREEN >= 4) {
             float *dst = (float *)ldsGeom;
             for (int i = threadIdx.x; i < P.ldsHeadFloats; i += blockDim.x) dst[i] = P.geomF[i];
             float *tail = dst + 4 * (size_t)P.ballMembersLds;
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
 
     // rayIntersectAvoid for one ray per lane (mainTracing.c:128-153): picks the walk the job was built for; returns
     // how many shapes the ray's avoid list removes from the brute-force count
-    auto closest = [&](const double o[3], const double d[3], int mode, int li, int depth, Hit &h) -> unsigned {
+    auto closest = [&](const double o[3], const double d[3], int mode, int li, int depth, double tLimit, Hit &h) -> unsigned {
         int avoidShape = -1;
         const unsigned char *avoidRow = nullptr;
         unsigned avoided = 0;
@@ -109,7 +110,11 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     int family = P.ballFamily;
                     if (mode == M_SHADOW) family = P.lightFamilyBase + li;
                     else if ((mode == M_INDEX || depth == 0) && P.cameraFamily >= 0) family = P.cameraFamily;
-                    closestHitFamilies<AVOID, EXACTLDS, SCREEN == 4>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, family, negThreshold, h);
+                    // level 5: only the coherent rays of a pixel's first level walk the families' tables
+                    if (SCREEN == 5 && (depth > 0 || family < 0))
+                        closestHitGrid<AVOID>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, tLimit, h);
+                    else
+                        closestHitFamilies<AVOID, EXACTLDS, SCREEN >= 4, SCREEN != 5>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, family, negThreshold, h);
                 } else if (SCREEN == 2) closestHitGrouped<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
                 else closestHitScreened<AVOID, LDSGEOM, EXACTLDS>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, h);
             } else {  // exact loop over the doubles in global memory
@@ -220,6 +225,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             double stk[kMaxDepth * kEntry];
             unsigned char flags[kMaxDepth];
             int rayReflects = 1;               // shouldReflect of the ray being traced (mainTracing.c:300)
+            double tLimit = INFINITY;          // shadow rays: ray parameter of the light (see closestHitGrid)
 
             auto startSample = [&](int s) {
                 double xo = colI, yo = rowJ;
@@ -242,6 +248,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 o[1] = loc[1] + .000001 * d[1];
                 o[2] = loc[2] + .000001 * d[2];
                 mode = M_SHADOW;
+                if (SCREEN == 5) tLimit = (L.loc[0] - o[0]) * d[0] + (L.loc[1] - o[1]) * d[1] + (L.loc[2] - o[2]) * d[2];
             };
 
             // maxDepth <= 0: shootRay returns black before it looks at the scene (mainTracing.c:302-306), for every
@@ -290,7 +297,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 const unsigned long long stamp0 = clock64();
 #endif
                 Hit h;
-                const unsigned avoided = closest(o, d, mode, li, depth, h);
+                const unsigned avoided = closest(o, d, mode, li, depth, mode == M_SHADOW ? tLimit : INFINITY, h);
                 rayCount++;
                 testCount += (unsigned)P.numShapes - avoided;
 #ifdef GRAFT_STAMPS
@@ -624,7 +631,7 @@ void readSettingsOnce() {
     if (gSettingsRead) return;
     gSettingsRead = true;
     if (const char *e = getenv("GRAFT_SCREEN"))
-        if (e[0] >= '0' && e[0] <= '4' && !e[1]) gSettings.screenCap = e[0] - '0';
+        if (e[0] >= '0' && e[0] <= '5' && !e[1]) gSettings.screenCap = e[0] - '0';
     if (const char *e = getenv("GRAFT_GROUP")) gSettings.groupSize = atoi(e);
     if (const char *e = getenv("GRAFT_PER_TICKET")) gSettings.tilesPerTicket = atoi(e) > 0 ? atoi(e) : 0;
     if (const char *e = getenv("GRAFT_PARK")) gSettings.park = atoi(e) != 0;
@@ -637,7 +644,8 @@ template <int A>
 TraceFn pickKernelPark(int screen, bool exactLds) {
     if (screen == 2) return exactLds ? traceKernel<A, true, 2, true, false, true, true> : traceKernel<A, true, 2, false, false, true, true>;
     if (screen == 3) return exactLds ? traceKernel<A, true, 3, true, false, true, true> : traceKernel<A, true, 3, false, false, true, true>;
-    return traceKernel<A, true, 4, false, false, true, true>;
+    if (screen == 4) return traceKernel<A, true, 4, false, false, true, true>;
+    return traceKernel<A, true, 5, false, false, true, true>;
 }
 
 template <int A, bool M>
@@ -647,7 +655,8 @@ TraceFn pickKernelA(bool lds, int screen, bool exactLds) {
     if (screen == 1) return exactLds ? traceKernel<A, true, 1, true, false, M> : traceKernel<A, true, 1, false, false, M>;
     if (screen == 2) return exactLds ? traceKernel<A, true, 2, true, false, M> : traceKernel<A, true, 2, false, false, M>;
     if (screen == 3) return exactLds ? traceKernel<A, true, 3, true, false, M> : traceKernel<A, true, 3, false, false, M>;
-    return traceKernel<A, true, 4, false, false, M>;
+    if (screen == 4) return traceKernel<A, true, 4, false, false, M>;
+    return traceKernel<A, true, 5, false, false, M>;
 }
 
 // Scenes with a transparent shape run the tree-walk kernels, built only for the general avoid mode, screen
@@ -856,7 +865,7 @@ GRAFT_API int graftDiagnosticSet(int which, int value) {
     readSettingsOnce();
     switch (which) {
         case GRAFT_DIAG_SCREEN_CAP:
-            if (value < 0 || value > 4) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: screen cap %d", value);
+            if (value < 0 || value > 5) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: screen cap %d", value);
             gSettings.screenCap = value;
             return GRAFT_OK;
         case GRAFT_DIAG_GROUP_SIZE:

@@ -19,7 +19,7 @@ namespace graft {
 
 // Diagnostic settings (A/B timing and the tests that run every screen level).  They never change a result.
 struct Settings {
-    int screenCap = 4;       // highest screen level a job may use
+    int screenCap = 5;       // highest screen level a job may use
     int groupSize = 0;       // spheres per group of the two-level screens, 0 = chosen per scene
     int tilesPerTicket = 0;  // tiles a wave draws at once, 0 = chosen per launch
     int park = 1;            // 1 = launches of one sample per pixel may park mirror rays and trace them in full waves
@@ -29,7 +29,7 @@ struct PackedJob {
     TraceParams P;                     // everything but the pointers, which bindImage() fills in
     std::vector<unsigned char> image;  // the device block, byte for byte
     size_t oGeom = 0, oGeomF = 0, oMember = 0, oRuns = 0, oMat = 0, oLights = 0, oMask = 0, oCol = 0, oRow = 0,
-           oCam = 0, oCursor = 0;
+           oCam = 0, oGrid = 0, oCursor = 0;
     int avoidMode = 0;
     int screen = 0;         // 0 = exact only, 1 = screen per sphere, 2 = two-level ball screen, 3/4 = per-family screens
     bool lds = false;       // hot table staged in LDS
@@ -49,6 +49,8 @@ struct TableCache {
     int groupSize = -1;
     bool haveBalls = false, ballsOk = false;
     TwoLevelTable balls;
+    bool haveGrid = false, gridOk = false;
+    GridTable grid;
     struct Cone {
         double apex[3], scale;
         TwoLevelTable table;
@@ -60,6 +62,7 @@ struct TableCache {
         sph = s;
         groupSize = g;
         haveBalls = ballsOk = false;
+        haveGrid = gridOk = false;
         cones.clear();
     }
     void makeRoom(size_t wanted) {  // call before a round of cone() calls, never between them
@@ -77,6 +80,53 @@ struct TableCache {
         return c.table;
     }
 };
+
+// Level 5: the cone families' group and third-level sections in LDS as at level 4 (member sections in global memory),
+// no ball family; rays outside the cone families walk a uniform grid whose cells, entries and per-sphere screen table
+// are staged behind the third-level sections.  `fam` = cone tables then the ball table (whose entries only pad the
+// interleaved table's stride here); `inter` = the interleaved table of all of them.  Returns false when the grid
+// cannot be built or the sections do not fit.
+inline bool packLevel5(TableCache &cache, const std::vector<double> &sph, size_t cones,
+                       const std::vector<const TwoLevelTable *> &fam, std::vector<float> &inter,
+                       std::vector<int> &interShape, TraceParams &P) {
+    if (!cache.haveGrid) {
+        cache.gridOk = packGrid(sph, cache.grid);
+        cache.haveGrid = true;
+        cache.builds++;
+    }
+    if (!cache.gridOk || cones == 0) return false;
+    const GridTable &G = cache.grid;
+    // the kernel reads blocks of family f at stride `families`: re-interleave the cone families alone
+    std::vector<const TwoLevelTable *> conesOnly(fam.begin(), fam.begin() + cones);
+    std::vector<float> table, supers;
+    std::vector<int> shapes;
+    interleaveFamilies(conesOnly, table, shapes);
+    interleaveSupers(conesOnly, supers);
+    const size_t headFloats = 4 * (size_t)conesOnly[0]->memberBase * cones;
+    const size_t words = headFloats + supers.size() + G.cells.size() + G.refs.size() / 2 + G.aos.size();
+    if (sizeof(float) * words > kLdsMax) return false;
+    P.ldsHeadFloats = (int)headFloats;
+    P.ballMembersLds = (int)(headFloats / 4);  // where the tail starts (float4 index)
+    P.ldsTailSrc = (int)table.size();
+    P.superLds = (int)(headFloats / 4);
+    P.superEntries = conesOnly[0]->superEntries;
+    P.gridNx = G.n[0]; P.gridNy = G.n[1]; P.gridNz = G.n[2];
+    P.gridCellsOff = (int)(sizeof(float) * (headFloats + supers.size()));
+    P.gridRefsOff = P.gridCellsOff + (int)(sizeof(unsigned) * G.cells.size());
+    P.gridAosOff = (P.gridRefsOff + (int)(sizeof(unsigned short) * G.refs.size()) + 15) & ~15;
+    const size_t tailWords = (size_t)(P.gridAosOff / 4) - headFloats + G.aos.size();
+    P.ldsTailFloats = (int)tailWords;
+    std::vector<float> tail(tailWords, 0.0f);
+    memcpy(tail.data(), supers.data(), sizeof(float) * supers.size());
+    memcpy((char *)tail.data() + (P.gridCellsOff - sizeof(float) * headFloats), G.cells.data(), sizeof(unsigned) * G.cells.size());
+    memcpy((char *)tail.data() + (P.gridRefsOff - sizeof(float) * headFloats), G.refs.data(), sizeof(unsigned short) * G.refs.size());
+    memcpy((char *)tail.data() + (P.gridAosOff - sizeof(float) * headFloats), G.aos.data(), sizeof(float) * G.aos.size());
+    if (sizeof(float) * (headFloats + tailWords) > kLdsMax) return false;
+    table.insert(table.end(), tail.begin(), tail.end());
+    inter.swap(table);
+    interShape.swap(shapes);
+    return true;
+}
 
 // Validate, pack shapes to per-kind geometry arrays + materials, avoid lists to indices, and build the screen
 // tables.  Replaces the implicit "read the globals" of launchRays (mainTracing.c:387-391).  Returns a GRAFT_* code
@@ -235,6 +285,8 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
             interleaveSupers(fam, supers);
             if (sizeof(float) * inter.size() <= kLdsMax) {
                 screen = 3;
+            } else if (screenCap >= 5 && packLevel5(cache, sph, apexes.size(), fam, inter, interShape, P)) {
+                screen = 5;
             } else if (screenCap >= 4 && sizeof(float) * (headFloats + ballMemberFloats + supers.size()) <= kLdsMax) {
                 // cone member sections stay in global memory; the ball family's member section and the third-level
                 // sections are appended to the table so that the kernel can stage them behind the group sections
@@ -252,7 +304,8 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
                 tableF.swap(inter);
                 memberShape.swap(interShape);
                 P.families = (int)fam.size();
-                P.ballFamily = (int)fam.size() - 1;
+                P.ballFamily = screen == 5 ? -1 : (int)fam.size() - 1;
+                if (screen == 5) P.families = (int)fam.size() - 1;
                 P.cameraFamily = lightBase ? 0 : -1;
                 P.lightFamilyBase = lightBase;
                 P.familyScale = scale;
@@ -277,7 +330,8 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     J.oCol = align(J.oMask + mask.size() + 1);
     J.oRow = align(J.oCol + sizeof(double) * view->nCols);
     J.oCam = align(J.oRow + sizeof(double) * view->nRows);
-    J.oCursor = align(J.oCam + sizeof(DevCamera));
+    J.oGrid = align(J.oCam + sizeof(DevCamera));
+    J.oCursor = align(J.oGrid + sizeof(DevGrid));
     const size_t total = J.oCursor + sizeof(int) * kCursors * kCursorStride + 256;
     std::vector<unsigned char> &host = J.image;
     host.assign(total, 0);
@@ -296,16 +350,21 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     memcpy(&host[J.oCol], view->colOffsets, sizeof(double) * view->nCols);
     memcpy(&host[J.oRow], view->rowOffsets, sizeof(double) * view->nRows);
     memcpy(&host[J.oCam], &cam, sizeof cam);
+    if (screen == 5) {
+        DevGrid g;
+        for (int a = 0; a < 3; ++a) { g.lo[a] = cache.grid.lo[a]; g.hi[a] = cache.grid.hi[a]; g.cs[a] = cache.grid.cs[a]; g.invCs[a] = cache.grid.invCs[a]; }
+        memcpy(&host[J.oGrid], &g, sizeof g);
+    }
 
     J.avoidMode = avoidMode;
     J.screen = screen;
     J.mirrors = mirrors;
-    const size_t tableBytes = screen == 4 ? sizeof(float) * ((size_t)P.ldsHeadFloats + P.ldsTailFloats)
+    const size_t tableBytes = screen >= 4 ? sizeof(float) * ((size_t)P.ldsHeadFloats + P.ldsTailFloats)
                             : screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)(P.geomDoubles + kGeomPad);
     const size_t exactBytes = sizeof(double) * (size_t)P.geomDoubles;
     J.lds = tableBytes <= kLdsMax;
     J.transp = transparent;
-    J.exactLds = !transparent && J.lds && screen && screen != 4 && ((tableBytes + 31) & ~(size_t)31) + exactBytes <= kLdsMax;
+    J.exactLds = !transparent && J.lds && screen && screen < 4 && ((tableBytes + 31) & ~(size_t)31) + exactBytes <= kLdsMax;
     P.exactLdsOffset = (int)((tableBytes + 31) & ~(size_t)31);
     J.ldsBytes = !J.lds ? 0 : J.exactLds ? P.exactLdsOffset + exactBytes : tableBytes;
     // workgroup size: as many workgroups per CU as the LDS footprint allows, 16 waves per CU in every case
@@ -327,6 +386,7 @@ inline TraceParams bindImage(const PackedJob &J, void *base) {
     P.colOff = (const double *)(b + J.oCol);
     P.rowOff = (const double *)(b + J.oRow);
     P.camera = (const DevCamera *)(b + J.oCam);
+    P.grid = (const DevGrid *)(b + J.oGrid);
     P.tileCursor = (int *)(b + J.oCursor);
     return P;
 }

@@ -305,6 +305,89 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
     }
 }
 
+// Uniform grid over the spheres for rays that pass through no fixed point (mirror rays and the shadow rays of their
+// hits): see closestHitGrid.  Every sphere is entered in every cell that its ball, grown by kGroupMargin, touches; a
+// point of a sphere's surface therefore lies in a cell that lists the sphere, and so does every point within the
+// margin of it -- which is what lets the walk step from cell to cell in ordinary floating point.  About one cell per
+// sphere, at most kGridMaxCells cells and 255 entries per cell.  cells[c] = first entry << 8 | entries; refs[] = sphere
+// numbers; aos[] = {cx, cy, cz, rho} per sphere in single precision, rho as in packScreenTable.
+constexpr int kGridMaxCells = 4096;
+struct GridTable {
+    double lo[3], hi[3], cs[3], invCs[3];
+    int n[3];
+    std::vector<unsigned> cells;
+    std::vector<unsigned short> refs;
+    std::vector<float> aos;
+};
+
+inline bool packGrid(const std::vector<double> &sph, GridTable &T) {
+    const int n = (int)(sph.size() / 4);
+    if (n < 64 || n > 65535) return false;
+    std::vector<double> rad(n);
+    for (int a = 0; a < 3; ++a) { T.lo[a] = INFINITY; T.hi[a] = -INFINITY; }
+    for (int k = 0; k < n; ++k) {
+        const double *c = &sph[4 * (size_t)k];
+        if (!(fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + sqrt(c[3]) < kGroupScale)) return false;  // also rejects NaN
+        rad[k] = sqrt(c[3]) * (1.0 + 1e-9) + kGroupMargin;
+        for (int a = 0; a < 3; ++a) {
+            T.lo[a] = fmin(T.lo[a], c[a] - rad[k]);
+            T.hi[a] = fmax(T.hi[a], c[a] + rad[k]);
+        }
+    }
+    double ext[3], volume = 1;
+    for (int a = 0; a < 3; ++a) {
+        T.lo[a] -= kGroupMargin; T.hi[a] += kGroupMargin;
+        ext[a] = T.hi[a] - T.lo[a];
+        volume *= ext[a];
+    }
+    const double edge = cbrt(volume / fmin((double)n, (double)kGridMaxCells));
+    for (int a = 0; a < 3; ++a) T.n[a] = (int)fmax(1.0, fmin(64.0, floor(ext[a] / edge + 0.5)));
+    while ((long long)T.n[0] * T.n[1] * T.n[2] > kGridMaxCells) {  // rounding went up: shrink the longest axis
+        int a = T.n[0] >= T.n[1] && T.n[0] >= T.n[2] ? 0 : T.n[1] >= T.n[2] ? 1 : 2;
+        T.n[a]--;
+    }
+    for (int a = 0; a < 3; ++a) { T.cs[a] = ext[a] / T.n[a]; T.invCs[a] = T.n[a] / ext[a]; }
+    const int cellsTotal = T.n[0] * T.n[1] * T.n[2];
+    std::vector<std::vector<unsigned short>> lists(cellsTotal);
+    for (int k = 0; k < n; ++k) {
+        const double *c = &sph[4 * (size_t)k];
+        int i0[3], i1[3];
+        for (int a = 0; a < 3; ++a) {  // one cell more on either side than the arithmetic says
+            i0[a] = std::max(0, (int)floor((c[a] - rad[k] - T.lo[a]) * T.invCs[a]) - 1);
+            i1[a] = std::min(T.n[a] - 1, (int)floor((c[a] + rad[k] - T.lo[a]) * T.invCs[a]) + 1);
+        }
+        for (int z = i0[2]; z <= i1[2]; ++z)
+            for (int y = i0[1]; y <= i1[1]; ++y)
+                for (int x = i0[0]; x <= i1[0]; ++x) {
+                    const int cell[3] = {x, y, z};
+                    double dist2 = 0;  // from the centre to the cell's box
+                    for (int a = 0; a < 3; ++a) {
+                        const double bl = T.lo[a] + cell[a] * T.cs[a], bh = T.lo[a] + (cell[a] + 1) * T.cs[a];
+                        const double gap = c[a] < bl ? bl - c[a] : c[a] > bh ? c[a] - bh : 0;
+                        dist2 += gap * gap;
+                    }
+                    const double reach = rad[k] + 1e-6 * (1 + rad[k]);
+                    if (dist2 <= reach * reach) lists[(z * T.n[1] + y) * T.n[0] + x].push_back((unsigned short)k);
+                }
+    }
+    T.cells.assign(cellsTotal, 0);
+    T.refs.clear();
+    for (int c = 0; c < cellsTotal; ++c) {
+        if (lists[c].size() > 255 || T.refs.size() >= (1u << 24)) return false;
+        T.cells[c] = (unsigned)(T.refs.size() << 8) | (unsigned)lists[c].size();
+        T.refs.insert(T.refs.end(), lists[c].begin(), lists[c].end());
+    }
+    if (T.refs.size() & 1) T.refs.push_back(0);
+    T.aos.assign(4 * (size_t)n, 0.0f);
+    for (int k = 0; k < n; ++k) {
+        const double *c = &sph[4 * (size_t)k];
+        float rho;
+        if (!screenRho(c, c[3], rho)) return false;
+        T.aos[4 * k] = (float)c[0]; T.aos[4 * k + 1] = (float)c[1]; T.aos[4 * k + 2] = (float)c[2]; T.aos[4 * k + 3] = rho;
+    }
+    return true;
+}
+
 // Interleave the tables of several ray families block by block (a block = 4 packed entries = 64 bytes): block b of
 // family f lands at float4 index 4 * (b * families + f), and the shape index of member entry i at i * families + f.
 // A lane then reads a block with one address and four fixed offsets, and lanes of one wave that trace rays of

@@ -67,6 +67,12 @@ static_assert(offsetof(DevCamera, camPos) == 8 * CAM_POS && offsetof(DevCamera, 
               offsetof(DevCamera, lrDen) == 8 * CAM_LRDEN && offsetof(DevCamera, background) == 8 * CAM_BACKGROUND &&
               offsetof(DevCamera, subStepY) == 8 * CAM_SUBY, "DevCamera layout");
 
+// Grid of closestHitGrid, read by scalar loads like the camera block: lo[3], hi[3], cell size[3], 1 / cell size[3].
+struct DevGrid {
+    double lo[3], hi[3], cs[3], invCs[3];
+};
+enum { GRID_LO = 0, GRID_HI = 3, GRID_CS = 6, GRID_INVCS = 9 };
+
 struct TraceParams {
     const DevCamera *camera;
     int projectionType, aliasing, numPasses, maxDepth;
@@ -92,6 +98,11 @@ struct TraceParams {
     // (float4 index superLds, superEntries entries per family, a multiple of 8)
     int ldsHeadFloats, ballMembersLds, ldsTailSrc, ldsTailFloats;
     int superLds, superEntries;
+    // SCREEN == 5: level 4 with a uniform grid in place of the ball family (cells, entries and the per-sphere screen
+    // table staged in LDS behind the third-level sections, at these byte offsets from the start of LDS)
+    int gridNx, gridNy, gridNz;
+    int gridCellsOff, gridRefsOff, gridAosOff;
+    const DevGrid *grid;
     const int *memberShape;    // grouped screen: shape index of every member-table entry, -1 = padding
     const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
     const double *geom;

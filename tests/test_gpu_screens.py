@@ -1,6 +1,6 @@
 """The conservative screens (single-precision per-sphere screen, two-level ball screen, per-family cone screens)
 must never change a result.  Random and adversarial sphere scenes, GPU against the CPU oracle, bit for bit, at
-every screen level (GRAFT_SCREEN = 0..4 caps the level a job may use; 0 is the plain double-precision loop)."""
+every screen level (the screen_cap setting, 0..5, caps the level a job may use; 0 is the plain double-precision loop)."""
 import numpy as np
 import pytest
 
@@ -33,7 +33,7 @@ def scene(seed, n, size=(64, 64), lights=3, radius=(5.0, 40.0), box=400.0, refl=
     return rt
 
 
-def check_all_levels(rt, levels=(0, 1, 2, 3, 4)):
+def check_all_levels(rt, levels=(0, 1, 2, 3, 4, 5)):
     want = ob.render(rt, threads=16, want_index=True)
     old = get_diagnostic("screen_cap")
     try:
@@ -116,7 +116,7 @@ def test_nearly_coincident_spheres(gpu):
         rt.sphereSetup(src.unif[3] * (1 + eps), [src.unif[0] + eps * 50, src.unif[1], src.unif[2] * (1 - eps)], n + k,
                        [.2, .9, .2], 0.3, 0.1, 1.0, 0.0)
     rt.numShapes = n + 30
-    check_all_levels(rt, levels=(0, 4))
+    check_all_levels(rt, levels=(0, 4, 5))
 
 
 def test_tiny_giant_and_far_spheres(gpu):
@@ -166,11 +166,11 @@ def large_scene(seed, n, **kw):
 
 
 def test_large_scenes_three_level_walk(gpu):
-    check_all_levels(large_scene(30, 1500, lights=5, refl=0.5, depth=3), levels=(0, 2, 4))
-    check_all_levels(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7, refl=0.5, depth=3), levels=(0, 4))
+    check_all_levels(large_scene(30, 1500, lights=5, refl=0.5, depth=3), levels=(0, 2, 4, 5))
+    check_all_levels(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7, refl=0.5, depth=3), levels=(0, 4, 5))
     rt = large_scene(32, 2100, lights=4)
     lightSetAvoid(rt.lights[2], [rt.shapes[11]], 1)
-    check_all_levels(rt, levels=(0, 4))
+    check_all_levels(rt, levels=(0, 4, 5))
 
 
 def test_groups_of_sixteen_and_other_sizes(gpu):
@@ -182,14 +182,14 @@ def test_groups_of_sixteen_and_other_sizes(gpu):
         for size in (4, 12, 32):
             set_diagnostic("group_size", size)
             check_all_levels(rt, levels=(2, 3))
-            check_all_levels(large_scene(30, 1500, lights=5, refl=0.5, depth=3), levels=(4,))
+            check_all_levels(large_scene(30, 1500, lights=5, refl=0.5, depth=3), levels=(4, 5))
     finally:
         set_diagnostic("group_size", old)
 
 
 def test_levels_are_actually_used(gpu):
     """The scenes above must really reach the screens they are meant to test."""
-    def level(rt, cap=4):
+    def level(rt, cap=5):
         old = set_diagnostic("screen_cap", cap)
         try:
             job = rt.create_job()
@@ -201,9 +201,9 @@ def test_levels_are_actually_used(gpu):
     assert level(scene(0, 96)) == 3
     assert [level(scene(0, 96), cap) for cap in (0, 1, 2, 3)] == [0, 1, 2, 3]
     assert level(scenes.workload("cfg4", 64, 64)) == 3 and level(scenes.workload("cfg3", 64, 64)) == 3
-    assert level(scenes.workload("cfg5", 64, 64)) == 4
-    assert level(large_scene(30, 1500, lights=5)) == 4 and level(large_scene(30, 1500, lights=5), 3) == 2
-    assert level(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7)) == 4
+    assert level(scenes.workload("cfg5", 64, 64)) == 5 and level(scenes.workload("cfg5", 64, 64), 4) == 4
+    assert level(large_scene(30, 1500, lights=5)) == 5 and level(large_scene(30, 1500, lights=5), 3) == 2
+    assert level(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7)) == 5
     assert level(scene(20, 100, lights=9)) == 2          # too many lights for the family tables
     assert level(scene(1, 40)) == 1                      # too few spheres for grouping
     assert level(scenes.default_scene()) == 1            # planes: per-sphere screen only
@@ -223,7 +223,7 @@ def test_parked_mirror_rays_change_nothing(gpu):
         for park in (0, 1):
             old_park = set_diagnostic("park", park)
             try:
-                for level in (2, 3, 4):
+                for level in (2, 3, 4, 5):
                     old = set_diagnostic("screen_cap", level)
                     try:
                         rgb, idx = rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_index=True)
