@@ -126,14 +126,13 @@ GRAFT_API const char *graftLastError(void);
 
 /* Diagnostic settings: for A/B timing and for the tests that run every kernel variant.  None of them changes a
  * result.  They start from the environment, which is read ONCE, at the first graftInit or graftDiagnostic* call
- * (GRAFT_SCREEN, GRAFT_GROUP, GRAFT_PER_TICKET, GRAFT_PARK); afterwards only graftDiagnosticSet changes them, and
+ * (GRAFT_SCREEN, GRAFT_GROUP, GRAFT_PER_TICKET); afterwards only graftDiagnosticSet changes them, and
  * graftDiagnosticGet reports the values in force.  A setting applies to jobs created (SCREEN_CAP, GROUP_SIZE) or
- * traces queued (TILES_PER_TICKET, PARK) after the call.  (No reference counterpart.) */
+ * traces queued (TILES_PER_TICKET) after the call.  (No reference counterpart.) */
 enum {
-    GRAFT_DIAG_SCREEN_CAP = 0,       /* 0..4: highest screen level a job may use (graftJobScreenLevel); default 4 */
+    GRAFT_DIAG_SCREEN_CAP = 0,       /* 0..5: highest screen level a job may use (graftJobScreenLevel); default 5 */
     GRAFT_DIAG_GROUP_SIZE = 1,       /* spheres per group of the two-level screens: 0 = chosen per scene, else 4..64, a multiple of 4 */
     GRAFT_DIAG_TILES_PER_TICKET = 2, /* 8x8 tiles a wave draws from the ticket counters at once: 0 = chosen per launch */
-    GRAFT_DIAG_PARK = 3,             /* 1 (default): one-sample-per-pixel traces of mirror scenes trace their mirror rays in full waves */
     GRAFT_DIAG_TABLE_BUILDS = 4      /* read-only: screen tables built so far (shows what a re-render re-used) */
 };
 GRAFT_API int graftDiagnosticSet(int which, int value);
@@ -210,8 +209,7 @@ GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, in
  * `stream` (NULL = the library's stream).  A scene + view that packs to more than the scratch block is refused with
  * GRAFT_ERR_UNSUPPORTED (4096 spheres with 4 lights at 16384 x 16384 pack to 1.2 MB).  Every call on a GPU uses that
  * GPU's one block, which keeps the previous call's contents until the next upload: calls on one stream follow each
- * other safely; calls of this entry point that overlap in time on one GPU (different streams) race.  One-sample-per-pixel traces never park mirror rays here (that needs queue
- * memory), so a frame may take longer than through graftJobTrace; results are identical. */
+ * other safely; calls of this entry point that overlap in time on one GPU (different streams) race. */
 #define GRAFT_NOALLOC_SCRATCH_BYTES (4u << 20)
 GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
                                      void *frameDevice, int32_t *hitIndexDevice, GraftCounters *countersDevice,

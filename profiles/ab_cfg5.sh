@@ -5,7 +5,7 @@ set -e
 OUT=${1:-gpurun_out/ab_cfg5}
 mkdir -p $OUT
 for screen in 4 5; do
-for park in 0 1; do
+for park in 0; do
   GRAFT_PARK=$park timeout -k 10 200 python bench.py --workload cfg5 --screen $screen --no-cpu --no-frame512 --steps 5 --warmup 2 > $OUT/s${screen}_park$park.json 2> $OUT/s${screen}_park$park.err
   python - $OUT/s${screen}_park$park.json <<'PY'
 import json,sys

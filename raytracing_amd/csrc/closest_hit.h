@@ -164,9 +164,8 @@ __device__ __forceinline__ double hitDistance(double t, double sx, double sy, do
 }
 
 // sphereIntersect (shapes.c:47-73) for sphere `shape` + the closest-hit update described above.
-__device__ __forceinline__ void exactSphereLazy(const double *geom, int shape, double sx, double sy, double sz, double dx,
+__device__ __forceinline__ void exactSphereLazy(const double4v c4, int shape, double sx, double sy, double sz, double dx,
                                                 double dy, double dz, double slackBase, double slackScale, Best &best) {
-    const double4v c4 = *(const double4v *)(geom + 4 * (size_t)shape);
     const double vx = sx - c4.x, vy = sy - c4.y, vz = sz - c4.z;
     const double b = vx * dx + vy * dy + vz * dz;
     const double vv = vx * vx + vy * vy + vz * vz;
@@ -198,6 +197,11 @@ __device__ __forceinline__ void exactSphereLazy(const double *geom, int shape, d
             }
         }
     }
+}
+
+__device__ __forceinline__ void exactSphereLazy(const double *geom, int shape, double sx, double sy, double sz, double dx,
+                                                double dy, double dz, double slackBase, double slackScale, Best &best) {
+    exactSphereLazy(*(const double4v *)(geom + 4 * (size_t)shape), shape, sx, sy, sz, dx, dy, dz, slackBase, slackScale, best);
 }
 
 // the Hit a walk returns for its best candidate: loc = s + t d as sphereIntersect forms it (shapes.c:67-68)
@@ -632,14 +636,15 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
 //
 // What makes it exact: a sphere the ray hits at parameter t has its hit point s + t d on its surface (to rounding),
 // hence inside a cell that lists it, and every point within kGroupMargin of that cell's box lies in a cell that lists
-// it as well.  The walk's idea of where the ray is differs from the true line by rounding only (double precision:
-// ~1e-9 of the margin), so among the cells it visits up to parameter t there is one that lists the sphere.  A lane
-// stops when its best hit lies before the exit of the cell just finished by more than `slack` (no unvisited cell can
-// hold a closer or equally close hit), or when it leaves the grid (every sphere lies inside).
+// it as well.  The walk's idea of where the ray is differs from the true line by rounding only (well inside the
+// margin, which grows with the coordinates: packGrid), so among the cells it visits up to parameter t there is one
+// that lists the sphere.  A lane stops when its best hit lies before the exit of the cell just finished by more than a
+// slack (no unvisited cell can hold a closer or equally close hit), or when it leaves the grid (every sphere lies
+// inside).
 //
 // tLimit < infinity marks a shadow ray towards a light at that parameter.  The caller only asks whether the closest
 // hit lies before or beyond the light (mainTracing.c:211-215: lit iff no hit, or the vector from the hit to the light
-// points backwards).  Any hit that is before the light by more than 1e-6 (relative and absolute) settles "before"
+// points backwards).  Any hit that is before the light by more than 1e-5 (relative and absolute) settles "before"
 // whichever sphere is closest, and nothing that starts beyond the light by that much can change "beyond"; only when
 // the best hit falls inside that band is the walk continued to the exact closest hit, which the caller then judges
 // with the reference's own arithmetic.
@@ -660,12 +665,15 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
     const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
     const int nx = P.gridNx, ny = P.gridNy, nz = P.gridNz;
 
-    // the part of the ray inside the grid's box, and per axis: step, parameter of the next cell face, parameter per cell
+    // The part of the ray inside the grid's box, and per axis: step, parameter of the next cell face, parameter per
+    // cell.  Set up in double precision, stepped in single: the walk's idea of the ray parameter is then off by at
+    // most (steps x half an ulp of t) ~ 4e-5 of the coordinate scale, which the grid's margin (packGrid) covers.
     double tEnter = 0, tLeave = INFINITY;
     bool alive = true;
-    double tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ, invX = 0, invY = 0, invZ = 0;
+    float tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ;
+    double invX = 0, invY = 0, invZ = 0;
     auto slab = [&](double o, double d, double lo, double hi, double &inv) {
-        if (fabs(d) > 1e-150) {  // (a smaller component moves the ray by nothing over any distance in the grid)
+        if (fabs(d) > 1e-30) {  // (a smaller component moves the ray by nothing over any distance in the grid)
             double r = __builtin_amdgcn_rcp(d);
             r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
             inv = r;
@@ -682,7 +690,7 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
     alive = alive && tEnter <= tLeave;
     int cx = 0, cy = 0, cz = 0, stepX = 0, stepY = 0, stepZ = 0;
     auto enter = [&](double o, double d, double inv, double lo, double cs, double invCs, int n, int &c, int &step,
-                     double &tMax, double &tDelta) {
+                     float &tMax, float &tDelta) {
         const double p = o + tEnter * d;
         double f = floor((p - lo) * invCs);
         f = f < 0 ? 0 : (f > (double)(n - 1) ? (double)(n - 1) : f);  // (false for NaN: cell 0)
@@ -690,8 +698,8 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
         if (inv != 0) {
             step = d > 0 ? 1 : -1;
             const double face = lo + (f + (d > 0 ? 1.0 : 0.0)) * cs;
-            tMax = (face - o) * inv;
-            tDelta = cs * fabs(inv);
+            tMax = (float)((face - o) * inv);
+            tDelta = (float)(cs * fabs(inv));
         } else {
             step = 0;
             tMax = INFINITY;
@@ -703,26 +711,39 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
     enter(sz, dz, invZ, G[GRID_LO + 2], G[GRID_CS + 2], G[GRID_INVCS + 2], nz, cz, stepZ, tMaxZ, tDeltaZ);
 
     const bool shadow = tLimit < INFINITY;
-    const double tSure = tLimit * (1 - 1e-6) - 1e-6, tStop = tLimit * (1 + 1e-6) + 1e-6;
+    const double tSure = tLimit * (1 - 1e-5) - 1e-5;
+    const float tStop = shadow ? (float)(tLimit * (1 + 1e-5) + 1e-5) : INFINITY;
+    // A lane goes on to the next cell while tExit < goOn: infinity until there is a hit, then the hit's parameter
+    // less a slack that covers single precision (or minus infinity once a shadow ray is known to be blocked).
+    float goOn = tStop;
     int ref = 0, refEnd = 0, pending = -1, last = -1;
+    double4v pendingGeom = {0, 0, 0, 0};  // fetched when the candidate is parked: the load's latency hides behind the walk
     auto openCell = [&]() {
         const unsigned r = cells[(cz * ny + cy) * nx + cx];
         ref = (int)(r >> 8);
         refEnd = ref + (int)(r & 255u);
     };
-    auto flush = [&]() {
-#ifdef GRAFT_STAMPS
-        if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
-#endif
-        if (pending >= 0) {
-            exactSphereLazy(geom, pending, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
-            pending = -1;
-        }
+    // single-precision screen (closestHitScreened's arithmetic): true = the exact discriminant is negative
+    auto miss = [&](const float4v e) {
+        const float vx = sxf - e.x, vy = syf - e.y, vz = szf - e.z;
+        float b = vx * dxf;
+        b = __builtin_fmaf(vy, dyf, b);
+        b = __builtin_fmaf(vz, dzf, b);
+        float vv = vx * vx;
+        vv = __builtin_fmaf(vy, vy, vv);
+        vv = __builtin_fmaf(vz, vz, vv);
+        return __builtin_fmaf(b, b, e.w - vv) < negThreshold;
+    };
+    auto avoided = [&](int k) {
+        if (AVOID == 1) return k == avoidShape;
+        if (AVOID == 2) return avoidRow != nullptr && avoidRow[k] != 0;
+        return false;
     };
     if (alive) openCell();
 #ifdef GRAFT_STAMPS  // diagnostic build: calls, iterations of the loop below, lanes alive in them, rounds of exact tests
-    const bool stampLeader = lane64() == (int)__builtin_ctzll(__ballot(1));
-    if (P.counters && stampLeader) { atomicAdd(P.counters + 12, 1ull); atomicAdd(P.counters + 13, (unsigned long long)__popcll(__ballot(1))); }
+    const unsigned long long stampOn = __ballot(1);
+    const bool stampLeader = lane64() == (int)__builtin_ctzll(stampOn);
+    if (P.counters && stampLeader) { atomicAdd(P.counters + 12, 1ull); atomicAdd(P.counters + 13, (unsigned long long)__popcll(stampOn)); }
     const unsigned long long stampGrid0 = clock64();
 #endif
     while (alive) {
@@ -732,51 +753,57 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
             if (lane64() == (int)__builtin_ctzll(on)) { atomicAdd(P.counters + 10, 1ull); atomicAdd(P.counters + 11, (unsigned long long)__popcll(on)); }
         }
 #endif
-        // up to two entries of the lane's cell through the screen
-#pragma unroll
-        for (int rep = 0; rep < 2; ++rep) {
-            int cand = -1;
-            if (ref < refEnd) {
-                const int k = refs[ref++];
-                if (k != last) {  // (a sphere that straddles two cells is listed in both, next to each other in time)
-                    last = k;
-                    const float4v e = aos[k];
-                    const float vx = sxf - e.x, vy = syf - e.y, vz = szf - e.z;
-                    float b = vx * dxf;
-                    b = __builtin_fmaf(vy, dyf, b);
-                    b = __builtin_fmaf(vz, dzf, b);
-                    float vv = vx * vx;
-                    vv = __builtin_fmaf(vy, vy, vv);
-                    vv = __builtin_fmaf(vz, vz, vv);
-                    const float val = __builtin_fmaf(b, b, e.w - vv);
-                    bool take = !(val < negThreshold);
-                    if (AVOID == 1) take = take && k != avoidShape;
-                    if (AVOID == 2) take = take && !(avoidRow && avoidRow[k]);
-                    if (take) cand = k;
-                }
-            }
-            if (__ballot(cand >= 0 && pending >= 0)) flush();
-            if (cand >= 0) pending = cand;
-        }
+        // Up to two entries of the lane's cell through the screen, without branches (the entry list is padded, so the
+        // reads are always inside it; what lies beyond the cell's entries is masked afterwards).
+        const int k0 = refs[ref], k1 = refs[ref + 1];
+        const float4v e0 = aos[k0], e1 = aos[k1];
+        const bool m0 = miss(e0), m1 = miss(e1);
+        int c0 = (ref < refEnd && k0 != last && !m0 && !avoided(k0)) ? k0 : -1;  // (a sphere that straddles two cells is
+        int c1 = (ref + 1 < refEnd && !m1 && !avoided(k1)) ? k1 : -1;            //  listed in both: skip the last one seen)
+        if (ref < refEnd) last = ref + 1 < refEnd ? k1 : k0;
+        ref += 2;
+        if (c0 < 0) { c0 = c1; c1 = -1; }
         const bool cellDone = ref >= refEnd;
-        if (__ballot(cellDone && pending >= 0)) flush();
-        if (cellDone) {
-            const double tExit = fmin(tMaxX, fmin(tMaxY, tMaxZ));
-            bool stop = tExit > tStop;  // (shadow rays only: tStop is infinite otherwise)
-            if (closest.shape >= 0) {
-                stop = stop || closest.t < tExit - (1e-7 * (fabs(tExit) + slackBase) + 1e-9);
-                stop = stop || (shadow && closest.t < tSure);
+        // One candidate is parked per lane.  The exact test runs (for every lane that has one parked) when a lane
+        // needs the slot for another candidate, and before a lane decides whether to go on to the next cell.
+        if (__ballot(c0 >= 0 || (pending >= 0 && cellDone))) {
+#pragma nounroll
+            for (int trip = 0; trip < 3; ++trip) {
+                if (__ballot(pending >= 0 && (c0 >= 0 || cellDone))) {
+#ifdef GRAFT_STAMPS
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
+#endif
+                    if (pending >= 0) {
+                        exactSphereLazy(pendingGeom, pending, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
+                        pending = -1;
+                        if (closest.shape >= 0) {
+                            const float guard = (float)(closest.t - (1e-5 * (fabs(closest.t) + slackBase) + 1e-6));
+                            goOn = shadow && closest.t < tSure ? -INFINITY : fminf(tStop, guard);
+                        }
+                    }
+                }
+                if (c0 >= 0) {
+                    pending = c0;
+                    pendingGeom = *(const double4v *)(geom + 4 * (size_t)c0);
+                    c0 = c1;
+                    c1 = -1;
+                }
+                if (!__ballot(c0 >= 0 || (pending >= 0 && cellDone))) break;
             }
+        }
+        if (cellDone) {
+            const float tExit = fminf(tMaxX, fminf(tMaxY, tMaxZ));
+            bool stop = !(tExit < goOn);
             if (!stop) {
-                if (tMaxX <= tMaxY && tMaxX <= tMaxZ) {
+                if (tMaxX == tExit) {
                     cx += stepX; tMaxX += tDeltaX;
-                    stop = cx < 0 || cx >= nx;
-                } else if (tMaxY <= tMaxZ) {
+                    stop = (unsigned)cx >= (unsigned)nx;
+                } else if (tMaxY == tExit) {
                     cy += stepY; tMaxY += tDeltaY;
-                    stop = cy < 0 || cy >= ny;
+                    stop = (unsigned)cy >= (unsigned)ny;
                 } else {
                     cz += stepZ; tMaxZ += tDeltaZ;
-                    stop = cz < 0 || cz >= nz || stepZ == 0;  // (all three parameters infinite: a ray that does not move)
+                    stop = (unsigned)cz >= (unsigned)nz || stepZ == 0;  // (all three infinite: a ray that does not move)
                 }
             }
             if (stop) alive = false;

@@ -51,15 +51,7 @@ namespace {
 // per-lane stack holds a tree walk (wider entries) instead of a chain.
 // MANYCURSORS: tickets come from kCursors counters instead of one (launches of cheap tiles, see below).  A
 // separate instantiation because the expensive-tile kernels lose 1-3 % to any change of this code (measured).
-// PARK (one sample per pixel, mirror shapes, no transparency; MANYCURSORS kernels only): a pixel whose primary hit
-// reflects is not followed down its mirror chain by the lane that found it.  After the tile's primary and shadow
-// rays the lane writes the mirror ray and the level's partial sum into the wave's own queue in global memory and
-// the wave moves on to its next tile; as soon as 64 pixels are queued the wave takes them back, one per lane, and
-// traces their chains with every lane busy (reflect() rays leave a tile in all directions, and only some pixels
-// of a tile have one: traced in place they keep a quarter of the lanes busy).  The value of a pixel does not
-// depend on which lane finishes it, and with one sample per pixel there is no sum over samples whose order could
-// change.  Only the wave that wrote a queue entry reads it, so no ordering between waves is involved.
-template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS, bool PARK = false>
+template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
     if (LDSGEOM) {
         if (SCREEN >= 4) {
@@ -154,20 +146,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     int usedUp = 0;  // counters found empty so far (wave-uniform)
     if (MANYCURSORS && P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
     int tile = 0, tileEnd = 0;
-    // PARK: the wave's queue of parked pixels.  Field f of slot i is the 8-byte word f * kParkSlots + i; fields 0-2
-    // origin and 3-5 direction of the mirror ray, 6-8 the level's partial sum, 9 = {shape hit, pixel of the band}.
-    // A tile adds at most 64 entries and the wave empties 64 whenever it holds that many, so slots stay below 128.
-    unsigned long long *const queue =
-        PARK ? P.parkQueue + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (kParkFields * kParkSlots) : nullptr;
-    int queued = 0;        // entries in the queue (wave-uniform)
-    bool tilesLeft = true;
     for (;;) {
-        int resumed = 0;  // PARK: lanes that take a parked pixel in this round instead of a tile's
-        if (PARK) {
-            if (queued >= 64 || (!tilesLeft && queued > 0)) resumed = queued < 64 ? queued : 64;
-            else if (!tilesLeft) break;  // every wave gets here: its tickets run out and its queue drains
-        }
-        if (resumed == 0 && tile >= tileEnd) {
+        if (tile >= tileEnd) {
             if (MANYCURSORS) {
                 const int numTickets = (P.numTiles + P.tilesPerTicket - 1) / P.tilesPerTicket;
                 if (!P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
@@ -177,23 +157,14 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     if (lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
                     ticket = __builtin_amdgcn_readfirstlane(nextTicket) * kCursors + cursor;
                 }
-                if (ticket >= numTickets) {  // every wave gets here: the counters only grow
-                    if (!PARK) break;
-                    tilesLeft = false;
-                    continue;
-                }
+                if (ticket >= numTickets) break;  // every wave gets here: the counters only grow
                 tile = ticket * P.tilesPerTicket;
                 tileEnd = min(tile + P.tilesPerTicket, P.numTiles);
                 if (P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
             } else {
                 const int ticket = __builtin_amdgcn_readfirstlane(nextTicket);
                 tile = ticket * P.tilesPerTicket;
-                if (tile >= P.numTiles) {  // every wave reaches this: the counter only grows
-                    if (!PARK) break;
-                    tilesLeft = false;
-                    tile = tileEnd = 0;
-                    continue;
-                }
+                if (tile >= P.numTiles) break;  // every wave reaches this: the counter only grows
                 tileEnd = min(tile + P.tilesPerTicket, P.numTiles);
                 if (lane == 0) nextTicket = atomicAdd(P.tileCursor, 1);
             }
@@ -202,18 +173,14 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         const int ix = tx * kTile + lx;
         const int by = ty * kTile + ly;  // row inside the band
         const int iy = P.row0 + by;
-        const bool inside = PARK && resumed ? lane < resumed : ix < P.nCols && by < P.bandRows;
-        // entries are read back by other lanes of the wave than those that stored them: the stores complete first
-        if (PARK && resumed) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        bool parkMe = false;  // PARK: this lane's pixel goes into the queue at the end of the round
+        const bool inside = ix < P.nCols && by < P.bandRows;
 
         const ConstDoubles cam = cameraView(P);
         double acc[3] = {cam[CAM_BACKGROUND], cam[CAM_BACKGROUND + 1], cam[CAM_BACKGROUND + 2]};  // mainTracing.c:395
         int firstIdx = -1;
         if (inside) {
-            double colI = 0, rowJ = 0;
-            if (!(PARK && resumed)) { colI = P.colOff[ix]; rowJ = P.rowOff[iy]; }
-            size_t pixel = (size_t)by * P.nCols + ix;
+            const double colI = P.colOff[ix], rowJ = P.rowOff[iy];
+            const size_t pixel = (size_t)by * P.nCols + ix;
             // per-lane machine state
             int mode, depth = 0, sample = 0, li = 0, sp = 0, hitIdx = -1, litLight = -1;
             double o[3], d[3];                 // current ray
@@ -254,28 +221,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             // maxDepth <= 0: shootRay returns black before it looks at the scene (mainTracing.c:302-306), for every
             // sample; with anti-aliasing the background-seeded sum (:395) takes n additions of zero
             const bool traceNothing = P.maxDepth <= 0;
-            if (PARK && resumed) {  // take a parked pixel back: its primary hit's level is entry 0 of the stack again
-                // (loads that go to the L2: the entry was stored by this wave, possibly through another lane)
-                unsigned long long *q = queue + (queued - resumed + lane);
-                auto word = [&](int f) { return __hip_atomic_load(q + f * kParkSlots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-                for (int c = 0; c < 3; ++c) {
-                    o[c] = __longlong_as_double((long long)word(c));
-                    d[c] = __longlong_as_double((long long)word(3 + c));
-                    stk[c] = __longlong_as_double((long long)word(6 + c));
-                }
-                const unsigned long long tag = word(9);
-                pixel = (size_t)(tag >> 32);
-                const DevMaterial &m = P.materials[(int)(tag & 0xffffffffu)];
-                for (int c = 0; c < 3; ++c) {
-                    const double t = (1 - .5) * (1.0 - m.color[c]);  // mainTracing.c:334-336
-                    stk[3 + c] = m.color[c] + t;
-                }
-                stk[6] = (1 - m.ambientLight) * m.reflectivity;  // mainTracing.c:359
-                flags[0] = F_MIRROR_PENDING;
-                sp = 1;
-                depth = 1;
-                mode = M_RADIANCE;
-            } else if (P.hitIndex && (P.aliasing || traceNothing)) {  // mask ray = the anti-aliasing-off ray of this pixel
+            if (P.hitIndex && (P.aliasing || traceNothing)) {  // mask ray = the anti-aliasing-off ray of this pixel
                 primaryRay(P, colI, rowJ, o, d);
                 mode = M_INDEX;
             } else if (traceNothing) {
@@ -414,10 +360,6 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                                 depth++;
                                 rayReflects = 1;  // reflection() passes shouldReflect = 1, :181
                                 mode = M_RADIANCE;
-                                if (PARK && depth == 1) {  // the primary hit's mirror ray: queue it, trace it later
-                                    parkMe = true;
-                                    mode = M_DONE;
-                                }
                             }
                         } else {  // glass without a mirror ray: reflectionRGB stays {0,0,0}; go straight to refraction
                             for (int c = 0; c < 3; ++c) lv[c] = (wRefl * 0.0) + part[c];
@@ -497,31 +439,10 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 const double n = (double)nSamples;
                 acc[0] = acc[0] / n; acc[1] = acc[1] / n; acc[2] = acc[2] / n;
             }
-            if (!(PARK && resumed) && P.hitIndex) P.hitIndex[pixel] = firstIdx;
-            if (PARK && parkMe) {
-                const unsigned long long mine = __ballot(1) & __ballot(parkMe);
-                const int slot = queued + __popcll(mine & ((1ull << lane) - 1));
-                unsigned long long *q = queue + slot;
-                for (int c = 0; c < 3; ++c) {
-                    q[c * kParkSlots] = (unsigned long long)__double_as_longlong(o[c]);
-                    q[(3 + c) * kParkSlots] = (unsigned long long)__double_as_longlong(d[c]);
-                    q[(6 + c) * kParkSlots] = (unsigned long long)__double_as_longlong(stk[c]);
-                }
-                q[9 * kParkSlots] = ((unsigned long long)pixel << 32) | (unsigned)hitIdx;
-            } else {
-                storeColor(pixel, acc);
-            }
+            if (P.hitIndex) P.hitIndex[pixel] = firstIdx;
+            storeColor(pixel, acc);
         }
-        if (PARK) {
-            if (resumed) {
-                queued -= resumed;
-            } else {
-                queued += __popcll(__ballot(parkMe));
-                ++tile;
-            }
-        } else {
-            ++tile;
-        }
+        ++tile;
     }
     if (P.counters) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -608,7 +529,6 @@ struct Device {
     hipStream_t stream = nullptr;
     Reusable frame, index, counters;      // device side of graftRenderRows' host buffers
     Reusable arena;                       // device block of the job graftRenderRows keeps between calls
-    Reusable parkQueue;                   // queues of parked pixels, one per wave of the largest PARK launch so far
     std::vector<unsigned char> cacheKey;  // the input that job was packed from
     GraftJob *cacheJob = nullptr;
     std::vector<const void *> configured;  // kernels whose dynamic-LDS limit has been raised on this device
@@ -634,19 +554,9 @@ void readSettingsOnce() {
         if (e[0] >= '0' && e[0] <= '5' && !e[1]) gSettings.screenCap = e[0] - '0';
     if (const char *e = getenv("GRAFT_GROUP")) gSettings.groupSize = atoi(e);
     if (const char *e = getenv("GRAFT_PER_TICKET")) gSettings.tilesPerTicket = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char *e = getenv("GRAFT_PARK")) gSettings.park = atoi(e) != 0;
 }
 
 typedef void (*TraceFn)(const TraceParams);
-
-// PARK kernels: many-counter launches of sphere-only scenes whose tables sit in LDS (screen levels 2 to 4)
-template <int A>
-TraceFn pickKernelPark(int screen, bool exactLds) {
-    if (screen == 2) return exactLds ? traceKernel<A, true, 2, true, false, true, true> : traceKernel<A, true, 2, false, false, true, true>;
-    if (screen == 3) return exactLds ? traceKernel<A, true, 3, true, false, true, true> : traceKernel<A, true, 3, false, false, true, true>;
-    if (screen == 4) return traceKernel<A, true, 4, false, false, true, true>;
-    return traceKernel<A, true, 5, false, false, true, true>;
-}
 
 template <int A, bool M>
 TraceFn pickKernelA(bool lds, int screen, bool exactLds) {
@@ -671,9 +581,7 @@ TraceFn pickKernelM(int avoidMode, bool lds, int screen, bool exactLds, bool tra
          : avoidMode == 1 ? pickKernelA<1, M>(lds, screen, exactLds) : pickKernelA<2, M>(lds, screen, exactLds);
 }
 
-TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool manyCursors, bool park) {
-    if (park) return avoidMode == 0 ? pickKernelPark<0>(screen, exactLds)
-                   : avoidMode == 1 ? pickKernelPark<1>(screen, exactLds) : pickKernelPark<2>(screen, exactLds);
+TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool manyCursors) {
     return manyCursors ? pickKernelM<true>(avoidMode, lds, screen, exactLds, transp)
                        : pickKernelM<false>(avoidMode, lds, screen, exactLds, transp);
 }
@@ -758,7 +666,6 @@ void releaseDevice(Device &D) {
     D.index.release();
     D.counters.release();
     D.arena.release();
-    D.parkQueue.release();
     D.configured.clear();
     D.stream = nullptr;
     D.ready = false;
@@ -766,7 +673,7 @@ void releaseDevice(Device &D) {
 
 // Queue one trace of rows [row0, row0 + nRows) of `job` on stream `s` of the job's device (which must be current).
 int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int32_t *hitIndex, GraftCounters *counters,
-                hipStream_t s, bool mayAllocate = true) {
+                hipStream_t s) {
     Device *D = job->dev;
     TraceParams P = job->P;
     P.row0 = row0; P.bandRows = nRows; P.format = format;
@@ -779,11 +686,7 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     // cheap tiles (few samples per pixel) are drawn several at a time and from several counters
     const int samples = P.aliasing ? P.numPasses * P.numPasses : 1;
     const bool manyCursors = samples < 4;
-    // one sample per pixel, mirrors, at least one bounce: the primary hits' mirror rays are parked and traced in full
-    // waves (needs queue memory: not on the path that must not allocate)
-    const bool park = gSettings.park && mayAllocate && samples == 1 && job->mirrors && !job->transp && P.maxDepth >= 2 &&
-                      job->lds && job->screen >= 2 && tiles * 64 < 0xffffffffLL;
-    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, manyCursors, park);
+    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, manyCursors);
     if (job->lds && std::find(D->configured.begin(), D->configured.end(), (const void *)fn) == D->configured.end()) {
         // more dynamic LDS than the default limit: raised once per kernel and device, when the kernel is first used
         HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
@@ -807,14 +710,6 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     if (gSettings.tilesPerTicket > 0) perTicket = gSettings.tilesPerTicket;  // diagnostics: forced ticket size
     P.tilesPerTicket = (int)perTicket;
     P.prefetchTickets = (tiles + perTicket - 1) / perTicket >= 8 * waves ? 1 : 0;
-    if (park) {
-        // One queue per wave.  Growing the buffer frees the old one, which an earlier launch may still be using.
-        const size_t need = (size_t)waves * kParkFields * kParkSlots * sizeof(unsigned long long);
-        if (need > D->parkQueue.cap) HIP_TRY(hipDeviceSynchronize());
-        hipError_t e = D->parkQueue.reserve(need);
-        if (e != hipSuccess) return fail(GRAFT_ERR_HIP, "hipMalloc(park queues, %zu): %s", need, hipGetErrorString(e));
-        P.parkQueue = (unsigned long long *)D->parkQueue.ptr;
-    }
     if (manyCursors) HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int) * kCursors * kCursorStride, s));
     else HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)P.tileCursor, grid * wavesPerBlock, 1, s));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(job->block), job->ldsBytes, s, P);
@@ -876,9 +771,6 @@ GRAFT_API int graftDiagnosticSet(int which, int value) {
             if (value < 0) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: tiles per ticket %d", value);
             gSettings.tilesPerTicket = value;
             return GRAFT_OK;
-        case GRAFT_DIAG_PARK:
-            gSettings.park = value != 0;
-            return GRAFT_OK;
         default:
             return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: unknown setting %d", which);
     }
@@ -890,7 +782,6 @@ GRAFT_API int graftDiagnosticGet(int which) {
         case GRAFT_DIAG_SCREEN_CAP: return gSettings.screenCap;
         case GRAFT_DIAG_GROUP_SIZE: return gSettings.groupSize;
         case GRAFT_DIAG_TILES_PER_TICKET: return gSettings.tilesPerTicket;
-        case GRAFT_DIAG_PARK: return gSettings.park;
         case GRAFT_DIAG_TABLE_BUILDS: return (int)(gTables.builds & 0x7fffffff);
         default: return -1;
     }
@@ -1114,7 +1005,7 @@ GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *v
     HIP_TRY(hipMemcpyAsync(D->scratch, D->scratchStage, J.image.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(D->scratchCopied, s));
     // (the ticket counters inside the block are set by the launch itself, behind the upload on the same stream)
-    return launchTrace(&job, row0, nRows, format, frameDevice, hitIndexDevice, countersDevice, s, false);
+    return launchTrace(&job, row0, nRows, format, frameDevice, hitIndexDevice, countersDevice, s);
 }
 
 static int probe(int which, const double *a, const double *b, double *out, size_t n) {

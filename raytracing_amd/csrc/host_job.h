@@ -22,7 +22,6 @@ struct Settings {
     int screenCap = 5;       // highest screen level a job may use
     int groupSize = 0;       // spheres per group of the two-level screens, 0 = chosen per scene
     int tilesPerTicket = 0;  // tiles a wave draws at once, 0 = chosen per launch
-    int park = 1;            // 1 = launches of one sample per pixel may park mirror rays and trace them in full waves
 };
 
 struct PackedJob {

@@ -306,12 +306,15 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
 }
 
 // Uniform grid over the spheres for rays that pass through no fixed point (mirror rays and the shadow rays of their
-// hits): see closestHitGrid.  Every sphere is entered in every cell that its ball, grown by kGroupMargin, touches; a
+// hits): see closestHitGrid.  Every sphere is entered in every cell that its ball, grown by a margin, touches; a
 // point of a sphere's surface therefore lies in a cell that lists the sphere, and so does every point within the
-// margin of it -- which is what lets the walk step from cell to cell in ordinary floating point.  About one cell per
+// margin of it -- which is what lets the walk step from cell to cell in single precision: the margin is
+// kGroupMargin + 1e-4 S for coordinates up to S <= kGridScale, against a worst-case drift of the stepped ray
+// parameter of 4e-5 S (192 steps of half an ulp of a parameter below 3.5 S).  About one cell per
 // sphere, at most kGridMaxCells cells and 255 entries per cell.  cells[c] = first entry << 8 | entries; refs[] = sphere
 // numbers; aos[] = {cx, cy, cz, rho} per sphere in single precision, rho as in packScreenTable.
 constexpr int kGridMaxCells = 4096;
+constexpr double kGridScale = 32768;
 struct GridTable {
     double lo[3], hi[3], cs[3], invCs[3];
     int n[3];
@@ -324,11 +327,18 @@ inline bool packGrid(const std::vector<double> &sph, GridTable &T) {
     const int n = (int)(sph.size() / 4);
     if (n < 64 || n > 65535) return false;
     std::vector<double> rad(n);
+    double scale = 0;
+    for (int k = 0; k < n; ++k) {
+        const double *c = &sph[4 * (size_t)k];
+        const double s1 = fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + sqrt(c[3]);
+        if (!(s1 < kGridScale)) return false;  // also rejects NaN
+        scale = fmax(scale, s1);
+    }
+    const double margin = kGroupMargin + 1e-4 * scale;
     for (int a = 0; a < 3; ++a) { T.lo[a] = INFINITY; T.hi[a] = -INFINITY; }
     for (int k = 0; k < n; ++k) {
         const double *c = &sph[4 * (size_t)k];
-        if (!(fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + sqrt(c[3]) < kGroupScale)) return false;  // also rejects NaN
-        rad[k] = sqrt(c[3]) * (1.0 + 1e-9) + kGroupMargin;
+        rad[k] = sqrt(c[3]) * (1.0 + 1e-9) + margin;
         for (int a = 0; a < 3; ++a) {
             T.lo[a] = fmin(T.lo[a], c[a] - rad[k]);
             T.hi[a] = fmax(T.hi[a], c[a] + rad[k]);
@@ -336,7 +346,7 @@ inline bool packGrid(const std::vector<double> &sph, GridTable &T) {
     }
     double ext[3], volume = 1;
     for (int a = 0; a < 3; ++a) {
-        T.lo[a] -= kGroupMargin; T.hi[a] += kGroupMargin;
+        T.lo[a] -= margin; T.hi[a] += margin;
         ext[a] = T.hi[a] - T.lo[a];
         volume *= ext[a];
     }
@@ -377,6 +387,8 @@ inline bool packGrid(const std::vector<double> &sph, GridTable &T) {
         T.cells[c] = (unsigned)(T.refs.size() << 8) | (unsigned)lists[c].size();
         T.refs.insert(T.refs.end(), lists[c].begin(), lists[c].end());
     }
+    T.refs.push_back(0);  // the walk reads two entries at a time, up to two past a cell's last
+    T.refs.push_back(0);
     if (T.refs.size() & 1) T.refs.push_back(0);
     T.aos.assign(4 * (size_t)n, 0.0f);
     for (int k = 0; k < n; ++k) {

@@ -19,8 +19,6 @@ constexpr int kSmallBlock = 256;    // scenes whose geometry fits a quarter of t
 #endif
 constexpr int kLargeBlock = GRAFT_LARGE_BLOCK;   // one workgroup per CU sharing up to the whole LDS
 constexpr int kGeomPad = 16;        // doubles of never-hit padding behind the packed geometry (the exact loop reads ahead)
-constexpr int kParkSlots = 128;     // entries of a wave's queue of parked pixels ...
-constexpr int kParkFields = 10;     // ... of this many 8-byte words each
 constexpr int kCursors = 16;        // ticket counters of the many-counter kernels ...
 constexpr int kCursorStride = 32;   // ... one per 128-byte line
 constexpr size_t kLdsSmall = 36 * 1024;
@@ -115,7 +113,6 @@ struct TraceParams {
     int *hitIndex;
     unsigned long long *counters;  // {rays, tests} or null
     int *tileCursor;
-    unsigned long long *parkQueue;  // PARK kernels: kParkFields * kParkSlots words per wave of the launch
 };
 
 extern __shared__ __attribute__((aligned(32))) double ldsGeom[];

@@ -211,27 +211,3 @@ def test_levels_are_actually_used(gpu):
     rt.shapes[3].transparency = 0.5
     assert level(rt) == 1                                # transparent: tree-walk kernels, per-sphere screen
 
-
-def test_parked_mirror_rays_change_nothing(gpu):
-    """One-sample-per-pixel traces of mirror scenes queue the primary hits' mirror rays and trace them in full waves
-    ("park" setting, on by default): the same frame with and without, at every level that parks, ragged frame sizes
-    (tiles partly outside), more and fewer pixels than one queue round, row bands, the index plane."""
-    for rt in (scene(60, 140, size=(61, 45), refl=0.7, depth=4), scene(61, 300, size=(128, 96), lights=2, refl=1.0, depth=6),
-               scene(62, 90, size=(8, 8), refl=0.9, depth=2), large_scene(63, 1400, lights=3, refl=0.5, depth=2),
-               scenes.workload("cfg5", 256, 64)):
-        want = ob.render(rt, threads=16, want_index=True)
-        for park in (0, 1):
-            old_park = set_diagnostic("park", park)
-            try:
-                for level in (2, 3, 4, 5):
-                    old = set_diagnostic("screen_cap", level)
-                    try:
-                        rgb, idx = rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_index=True)
-                        assert np.array_equal(idx, want["index"]), (park, level)
-                        assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64)), (park, level)
-                        part = rt.render_rows(5, rt.HEIGHT - 6, GRAFT_OUT_F64_RGB)
-                        assert np.array_equal(part.view(np.uint64), want["rgb"][5:rt.HEIGHT - 1].view(np.uint64)), (park, level)
-                    finally:
-                        set_diagnostic("screen_cap", old)
-            finally:
-                set_diagnostic("park", old_park)
