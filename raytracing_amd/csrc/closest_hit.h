@@ -653,7 +653,8 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
                                                double dz, int avoidShape, const unsigned char *avoidRow,
                                                float negThreshold, double tLimit, Hit &h) {
     const ConstDoubles G = (ConstDoubles)(unsigned long long)P.grid;
-    const unsigned *cells = (const unsigned *)((const char *)ldsGeom + P.gridCellsOff);
+    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+    const uint2v *cells = (const uint2v *)((const char *)ldsGeom + P.gridCellsOff);
     const unsigned short *refs = (const unsigned short *)((const char *)ldsGeom + P.gridRefsOff);
     const float4v *aos = (const float4v *)((const char *)ldsGeom + P.gridAosOff);
     const double *geom = P.geom;
@@ -716,12 +717,16 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
     // A lane goes on to the next cell while tExit < goOn: infinity until there is a hit, then the hit's parameter
     // less a slack that covers single precision (or minus infinity once a shadow ray is known to be blocked).
     float goOn = tStop;
-    int ref = 0, refEnd = 0, pending = -1, last = -1;
+    // the lane's cell: entries not yet looked at, the next two of them, and where the ones after those are listed
+    int left = 0, kA = 0, kB = 0, ref = 0;
+    int pending = -1, last = -1;
     double4v pendingGeom = {0, 0, 0, 0};  // fetched when the candidate is parked: the load's latency hides behind the walk
     auto openCell = [&]() {
-        const unsigned r = cells[(cz * ny + cy) * nx + cx];
-        ref = (int)(r >> 8);
-        refEnd = ref + (int)(r & 255u);
+        const uint2v w = cells[(cz * ny + cy) * nx + cx];
+        ref = (int)(w.x >> 8);
+        left = (int)(w.x & 255u);
+        kA = (int)(w.y & 0xffffu);
+        kB = (int)(w.y >> 16);
     };
     // single-precision screen (closestHitScreened's arithmetic): true = the exact discriminant is negative
     auto miss = [&](const float4v e) {
@@ -755,15 +760,18 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
 #endif
         // Up to two entries of the lane's cell through the screen, without branches (the entry list is padded, so the
         // reads are always inside it; what lies beyond the cell's entries is masked afterwards).
-        const int k0 = refs[ref], k1 = refs[ref + 1];
+        const int k0 = kA, k1 = kB;
         const float4v e0 = aos[k0], e1 = aos[k1];
+        kA = refs[ref];  // the pair after this one (read in any case: the list is padded; a new cell overwrites it)
+        kB = refs[ref + 1];
         const bool m0 = miss(e0), m1 = miss(e1);
-        int c0 = (ref < refEnd && k0 != last && !m0 && !avoided(k0)) ? k0 : -1;  // (a sphere that straddles two cells is
-        int c1 = (ref + 1 < refEnd && !m1 && !avoided(k1)) ? k1 : -1;            //  listed in both: skip the last one seen)
-        if (ref < refEnd) last = ref + 1 < refEnd ? k1 : k0;
+        int c0 = (left > 0 && k0 != last && !m0 && !avoided(k0)) ? k0 : -1;  // (a sphere that straddles two cells is
+        int c1 = (left > 1 && !m1 && !avoided(k1)) ? k1 : -1;                //  listed in both: skip the last one seen)
+        if (left > 0) last = left > 1 ? k1 : k0;
+        left -= 2;
         ref += 2;
         if (c0 < 0) { c0 = c1; c1 = -1; }
-        const bool cellDone = ref >= refEnd;
+        const bool cellDone = left <= 0;
         // One candidate is parked per lane.  The exact test runs (for every lane that has one parked) when a lane
         // needs the slot for another candidate, and before a lane decides whether to go on to the next cell.
         if (__ballot(c0 >= 0 || (pending >= 0 && cellDone))) {

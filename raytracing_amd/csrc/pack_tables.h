@@ -311,8 +311,10 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
 // margin of it -- which is what lets the walk step from cell to cell in single precision: the margin is
 // kGroupMargin + 1e-4 S for coordinates up to S <= kGridScale, against a worst-case drift of the stepped ray
 // parameter of 4e-5 S (192 steps of half an ulp of a parameter below 3.5 S).  About one cell per
-// sphere, at most kGridMaxCells cells and 255 entries per cell.  cells[c] = first entry << 8 | entries; refs[] = sphere
-// numbers; aos[] = {cx, cy, cz, rho} per sphere in single precision, rho as in packScreenTable.
+// sphere, at most kGridMaxCells cells and 255 entries per cell.  A cell is two words: {first << 8 | entries, its first
+// two sphere numbers (16 bits each)}; refs[first ...] holds the cell's THIRD and later entries, so that the walk reaches
+// the spheres of most cells with one read less; aos[] = {cx, cy, cz, rho} per sphere in single precision, rho as in
+// packScreenTable.
 constexpr int kGridMaxCells = 4096;
 constexpr double kGridScale = 32768;
 struct GridTable {
@@ -380,12 +382,14 @@ inline bool packGrid(const std::vector<double> &sph, GridTable &T) {
                     if (dist2 <= reach * reach) lists[(z * T.n[1] + y) * T.n[0] + x].push_back((unsigned short)k);
                 }
     }
-    T.cells.assign(cellsTotal, 0);
+    T.cells.assign(2 * (size_t)cellsTotal, 0);
     T.refs.clear();
     for (int c = 0; c < cellsTotal; ++c) {
-        if (lists[c].size() > 255 || T.refs.size() >= (1u << 24)) return false;
-        T.cells[c] = (unsigned)(T.refs.size() << 8) | (unsigned)lists[c].size();
-        T.refs.insert(T.refs.end(), lists[c].begin(), lists[c].end());
+        const std::vector<unsigned short> &l = lists[c];
+        if (l.size() > 255 || T.refs.size() >= (1u << 24)) return false;
+        T.cells[2 * c] = (unsigned)(T.refs.size() << 8) | (unsigned)l.size();
+        T.cells[2 * c + 1] = (l.size() > 0 ? l[0] : 0u) | ((l.size() > 1 ? l[1] : 0u) << 16);
+        if (l.size() > 2) T.refs.insert(T.refs.end(), l.begin() + 2, l.end());
     }
     T.refs.push_back(0);  // the walk reads two entries at a time, up to two past a cell's last
     T.refs.push_back(0);
