@@ -5,6 +5,7 @@ the kernel evaluates the reference's operations in the reference's order without
 """
 import numpy as np
 import pytest
+import torch  # before the HIP library touches the GPU: torch finds no device when it is imported afterwards
 
 import oracle_binding as ob
 from raytracing_amd import scenes
@@ -130,14 +131,48 @@ def test_device_sqrt_and_divide_are_correctly_rounded(gpu):
 
 def test_full_size_rows_match_oracle(gpu):
     """At the full frame sizes of the measured workloads the oracle cannot trace the whole frame in seconds:
-    compare evenly spaced whole rows bit-for-bit instead."""
-    for name, rows in (("cfg3", (0, 1377, 2048, 4095)), ("cfg5", (4099,)), ("cfg4", (8191,))):
+    compare evenly spaced whole rows (first and last included) bit-for-bit instead."""
+    for name, count in (("cfg3", 12), ("cfg5", 24), ("cfg4", 10)):
         rt = scenes.workload(name)
+        rows = sorted(set([0, rt.HEIGHT - 1] + [int((i + 0.37) * rt.HEIGHT / count) for i in range(count)]))
         for r in rows:
             want = ob.render(rt, r, 1, threads=THREADS, want_index=True)
             rgb, idx = rt.render_rows(r, 1, GRAFT_OUT_F64_RGB, want_index=True)
             assert np.array_equal(idx, want["index"]), (name, r)
             assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64)), (name, r)
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg5", "cfg4"])
+def test_full_size_frames_equal_the_exact_loop(gpu, name):
+    """Whole frames at the measured sizes: the job's own screen level against the plain double-precision loop
+    (screen cap 0), every pixel's doubles and closest-shape index, compared on the device.  A self-comparison of the
+    product: it adds to the oracle rows above (the exact loop is what those rows pin), it does not replace them."""
+    from raytracing_amd import get_diagnostic, set_diagnostic
+    rt = scenes.workload(name)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    H, W = rt.HEIGHT, rt.WIDTH
+    band = 2048  # rows per comparison: two bands of doubles and indices stay well inside device memory
+    old = get_diagnostic("screen_cap")
+    try:
+        jobs = []
+        for cap in (0, old):
+            set_diagnostic("screen_cap", cap)
+            jobs.append(rt.create_job())
+        assert jobs[0].screen_level() == 0 and jobs[1].screen_level() >= 3
+        bufs = [(torch.empty((band, W, 3), dtype=torch.float64, device=dev),
+                 torch.empty((band, W), dtype=torch.int32, device=dev)) for _ in jobs]
+        for r0 in range(0, H, band):
+            n = min(band, H - r0)
+            for job, (rgb, idx) in zip(jobs, bufs):
+                job.trace(r0, n, GRAFT_OUT_F64_RGB, rgb.data_ptr(), idx.data_ptr(), None, stream)
+            torch.cuda.synchronize()
+            assert torch.equal(bufs[0][1][:n], bufs[1][1][:n]), (name, r0, "index")
+            assert torch.equal(bufs[0][0][:n].view(torch.int64), bufs[1][0][:n].view(torch.int64)), (name, r0, "rgb")
+        for job in jobs:
+            job.close()
+    finally:
+        set_diagnostic("screen_cap", old)
 
 
 def test_errors_are_reported(gpu):
