@@ -215,6 +215,25 @@ GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *v
                                      void *frameDevice, int32_t *hitIndexDevice, GraftCounters *countersDevice,
                                      void *stream);
 
+/* ---- several GPUs driven by one process ------------------------------------------------------------------ */
+
+/* The reference is single-threaded and knows no device (mainTracing.c:387-443); these entry points let its one host
+ * thread spread a frame over the GPUs of a node.  Rows are cut into tile-aligned pieces dealt round-robin (rows differ
+ * in cost; dealing pieces of every part of the frame to every GPU evens that out), every GPU holds the whole packed
+ * scene, and the pieces are assembled in GPU 0's memory by RCCL send/recv over xGMI (one communicator per GPU from
+ * ncclCommInitAll; librccl.so is loaded when more than one GPU is asked for), each round of transfers hidden behind
+ * the tracing of the next round's pieces.
+ *
+ * graftInitDevices binds GPUs 0 .. nDevices-1 (GPU 0 is the root and the device of the single-GPU entry points; it is
+ * graftInit(0) when nDevices is 1).  graftFramePieces is the piece list (pure host arithmetic; returns the number of
+ * pieces, writes at most `cap`): piece k covers rows [firstRow[k], firstRow[k] + rows[k]) and belongs to GPU
+ * owner[k].  graftRenderFrameMulti is graftRenderRows for the whole frame over all bound GPUs, host buffers out;
+ * with one GPU bound it IS graftRenderRows. */
+GRAFT_API int graftInitDevices(int nDevices);
+GRAFT_API int graftFramePieces(int nRows, int nDevices, int piecesPerDevice, int *firstRow, int *rows, int *owner, int cap);
+GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *view, int format, int piecesPerDevice,
+                                    void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost);
+
 /* Write a host frame (row iy = 0 is the BOTTOM row, as pixSetRGB's y: 000pixel.h:53-55) as a binary PPM (P6, top
  * row first), quantising with q(v) = (uint8)(min(max(v,0),1)*255 + 0.5) where the format is not already 8 bit.
  * For headless runs: the reference can only show its frame in a window (000pixel.h:31-39). */

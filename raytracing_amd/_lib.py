@@ -87,6 +87,10 @@ lib.graftRenderRows.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTER(Graft
 lib.graftRenderRowsNoAlloc.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTER(GraftView), ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]
+lib.graftInitDevices.argtypes = [ctypes.c_int]
+lib.graftFramePieces.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p, ctypes.c_int]
+lib.graftRenderFrameMulti.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTER(GraftView), ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 lib.graftWritePPM.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 lib.graftDiagnosticSet.argtypes = [ctypes.c_int, ctypes.c_int]
 lib.graftDiagnosticGet.argtypes = [ctypes.c_int]

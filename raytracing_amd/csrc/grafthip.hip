@@ -10,6 +10,9 @@
 // The recursion of shootRay (reference mainTracing.c:300-372) is a per-lane state machine with ONE
 // closest-hit site, so lanes that trace primary, shadow and reflection rays share the hot loop.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is loaded when a second GPU is asked for
+
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -537,7 +540,27 @@ struct Device {
     unsigned char *scratch = nullptr;
     unsigned char *scratchStage = nullptr;
     hipEvent_t scratchCopied = nullptr;
+    // graftRenderFrameMulti: a second stream (the root receives on it while it traces on `stream`), the event that
+    // orders it behind `stream`, this device's rank in the communicator and its pieces' buffers
+    hipStream_t moveStream = nullptr;
+    hipEvent_t traced = nullptr;
+    ncclComm_t comm = nullptr;
+    Reusable pieces, pieceIndex;
 };
+
+// RCCL, loaded on demand (a process that drives one GPU never needs it)
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) commInitAll = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclGroupStart) groupStart = nullptr;
+    decltype(&ncclGroupEnd) groupEnd = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGetErrorString) errorString = nullptr;
+};
+Rccl gRccl;
+int gMultiDevices = 0;  // devices 0 .. gMultiDevices-1 bound by graftInitDevices
 
 Device gDevices[kMaxDevices];
 Device *gBound = nullptr;  // the device of graftInit: the single-device entry points work on it
@@ -654,6 +677,14 @@ void releaseDevice(Device &D) {
         (void)hipStreamSynchronize(D.stream);
         (void)hipStreamDestroy(D.stream);
     }
+    if (D.comm && gRccl.commDestroy) (void)gRccl.commDestroy(D.comm);
+    D.comm = nullptr;
+    if (D.moveStream) (void)hipStreamDestroy(D.moveStream);
+    if (D.traced) (void)hipEventDestroy(D.traced);
+    D.moveStream = nullptr;
+    D.traced = nullptr;
+    D.pieces.release();
+    D.pieceIndex.release();
     if (D.scratchCopied) (void)hipEventDestroy(D.scratchCopied);
     if (D.scratchStage) (void)hipHostFree(D.scratchStage);
     D.scratchCopied = nullptr;
@@ -752,6 +783,7 @@ GRAFT_API int graftInit(int device) {
 GRAFT_API void graftShutdown(void) {
     for (Device &D : gDevices) releaseDevice(D);
     gBound = nullptr;
+    gMultiDevices = 0;
 }
 
 GRAFT_API const char *graftLastError(void) { return gError; }
@@ -1006,6 +1038,193 @@ GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *v
     HIP_TRY(hipEventRecord(D->scratchCopied, s));
     // (the ticket counters inside the block are set by the launch itself, behind the upload on the same stream)
     return launchTrace(&job, row0, nRows, format, frameDevice, hitIndexDevice, countersDevice, s);
+}
+
+// ---- several GPUs driven by one process ----
+
+GRAFT_API int graftFramePieces(int nRows, int nDevices, int piecesPerDevice, int *firstRow, int *rows, int *owner, int cap) {
+    if (nRows <= 0 || nDevices <= 0) return -1;
+    const int tiles = (nRows + kTile - 1) / kTile;
+    int count = nDevices * (piecesPerDevice > 1 ? piecesPerDevice : 1);
+    if (count > tiles) count = tiles;
+    if (count < 1) count = 1;
+    int out = 0;
+    for (int k = 0; k < count; ++k) {
+        const int r0 = (int)((long long)k * tiles / count) * kTile;
+        int r1 = (int)((long long)(k + 1) * tiles / count) * kTile;
+        if (r1 > nRows) r1 = nRows;
+        if (r1 <= r0) continue;
+        if (out < cap) {
+            if (firstRow) firstRow[out] = r0;
+            if (rows) rows[out] = r1 - r0;
+            if (owner) owner[out] = k % nDevices;
+        }
+        ++out;
+    }
+    return out;
+}
+
+GRAFT_API int graftInitDevices(int nDevices) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (nDevices < 1 || nDevices > n || nDevices > kMaxDevices)
+        return fail(GRAFT_ERR_ARG, "graftInitDevices: %d devices asked for, %d present (at most %d)", nDevices, n, kMaxDevices);
+    if (gBound && gBound->id != 0) return fail(GRAFT_ERR_STATE, "graftInitDevices: already bound to device %d (device 0 is the root)", gBound->id);
+    if (gMultiDevices >= nDevices) return GRAFT_OK;
+    for (int d = 0; d < nDevices; ++d) {
+        Device *D = nullptr;
+        const int rc = initDevice(d, &D);
+        if (rc != GRAFT_OK) return rc;
+        HIP_TRY(hipSetDevice(d));
+        if (!D->moveStream) HIP_TRY(hipStreamCreateWithFlags(&D->moveStream, hipStreamNonBlocking));
+        if (!D->traced) HIP_TRY(hipEventCreateWithFlags(&D->traced, hipEventDisableTiming));
+    }
+    if (nDevices > 1) {
+        if (!gRccl.handle) {
+            void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+            if (!h) return fail(GRAFT_ERR_UNSUPPORTED, "graftInitDevices: cannot load librccl.so: %s", dlerror());
+            gRccl.commInitAll = (decltype(gRccl.commInitAll))dlsym(h, "ncclCommInitAll");
+            gRccl.commDestroy = (decltype(gRccl.commDestroy))dlsym(h, "ncclCommDestroy");
+            gRccl.groupStart = (decltype(gRccl.groupStart))dlsym(h, "ncclGroupStart");
+            gRccl.groupEnd = (decltype(gRccl.groupEnd))dlsym(h, "ncclGroupEnd");
+            gRccl.send = (decltype(gRccl.send))dlsym(h, "ncclSend");
+            gRccl.recv = (decltype(gRccl.recv))dlsym(h, "ncclRecv");
+            gRccl.errorString = (decltype(gRccl.errorString))dlsym(h, "ncclGetErrorString");
+            if (!gRccl.commInitAll || !gRccl.commDestroy || !gRccl.groupStart || !gRccl.groupEnd || !gRccl.send ||
+                !gRccl.recv || !gRccl.errorString) {
+                dlclose(h);
+                return fail(GRAFT_ERR_UNSUPPORTED, "graftInitDevices: librccl.so lacks an entry point");
+            }
+            gRccl.handle = h;
+        }
+        for (int d = 0; d < gMultiDevices; ++d)  // a smaller communicator from an earlier call
+            if (gDevices[d].comm) { (void)gRccl.commDestroy(gDevices[d].comm); gDevices[d].comm = nullptr; }
+        ncclComm_t comms[kMaxDevices];
+        int ids[kMaxDevices];
+        for (int d = 0; d < nDevices; ++d) ids[d] = d;
+        const ncclResult_t r = gRccl.commInitAll(comms, nDevices, ids);
+        if (r != ncclSuccess) return fail(GRAFT_ERR_HIP, "ncclCommInitAll(%d): %s", nDevices, gRccl.errorString(r));
+        for (int d = 0; d < nDevices; ++d) gDevices[d].comm = comms[d];
+    }
+    HIP_TRY(hipSetDevice(0));
+    gBound = &gDevices[0];
+    gMultiDevices = nDevices;
+    return GRAFT_OK;
+}
+
+#define NCCL_TRY(expr)                                                                                    \
+    do {                                                                                                  \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != ncclSuccess) { rc = fail(GRAFT_ERR_HIP, "%s: %s", #expr, gRccl.errorString(r_)); goto done; } \
+    } while (0)
+#define HIP_GO(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) { rc = fail(GRAFT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); goto done; } \
+    } while (0)
+
+GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *view, int format, int piecesPerDevice,
+                                    void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost) {
+    if (!frameHost) return fail(GRAFT_ERR_ARG, "graftRenderFrameMulti: null frame");
+    if (gMultiDevices < 1) return fail(GRAFT_ERR_STATE, "graftRenderFrameMulti: call graftInitDevices first");
+    const size_t pixelBytes = graftPixelBytes(format);
+    if (pixelBytes == 0) return fail(GRAFT_ERR_ARG, "graftRenderFrameMulti: unknown format %d", format);
+    const int G = gMultiDevices;
+    if (G == 1) {  // one GPU: exactly graftRenderRows
+        if (!view) return fail(GRAFT_ERR_ARG, "graftRenderFrameMulti: null view");
+        return graftRenderRows(scene, view, 0, view->nRows, format, frameHost, hitIndexHost, countersHost);
+    }
+    int rc = GRAFT_OK;
+    GraftJob *jobs[kMaxDevices] = {nullptr};
+    std::vector<int> first, count, owner;
+    std::vector<size_t> at;  // a piece's first row inside its owner's buffer
+    GraftCounters sum = {0, 0};
+    Device &root = gDevices[0];
+    int nPieces = 0, rounds = 0, nCols = 0, nRows = 0;
+    size_t ownedRows[kMaxDevices] = {0};
+    // every device packs (or finds in its cache) the same job
+    for (int d = 0; d < G; ++d) {
+        HIP_GO(hipSetDevice(d));
+        if ((rc = cachedJob(&gDevices[d], scene, view, &jobs[d])) != GRAFT_OK) goto done;
+    }
+    nCols = jobs[0]->P.nCols;
+    nRows = jobs[0]->P.nRows;
+    nPieces = graftFramePieces(nRows, G, piecesPerDevice, nullptr, nullptr, nullptr, 0);
+    first.resize(nPieces); count.resize(nPieces); owner.resize(nPieces); at.resize(nPieces);
+    graftFramePieces(nRows, G, piecesPerDevice, first.data(), count.data(), owner.data(), nPieces);
+    for (int k = 0; k < nPieces; ++k) {
+        at[k] = ownedRows[owner[k]];
+        ownedRows[owner[k]] += (size_t)count[k];
+    }
+    // buffers: the root holds the whole frame, every other device its own pieces
+    for (int d = 0; d < G; ++d) {
+        Device &D = gDevices[d];
+        HIP_GO(hipSetDevice(d));
+        const size_t rowsHere = d == 0 ? (size_t)nRows : ownedRows[d];
+        HIP_GO((d == 0 ? D.frame : D.pieces).reserve(rowsHere * nCols * pixelBytes + 16));
+        if (hitIndexHost) HIP_GO((d == 0 ? D.index : D.pieceIndex).reserve(rowsHere * nCols * 4 + 16));
+        if (countersHost) {
+            HIP_GO(D.counters.reserve(sizeof(GraftCounters)));
+            HIP_GO(hipMemsetAsync(D.counters.ptr, 0, sizeof(GraftCounters), D.stream));
+        }
+    }
+    // Round c: every device queues the kernel of its c-th piece; then one group of transfers moves the pieces of round
+    // c to the root (each sender's transfer is ordered behind its kernel through its `traced` event and runs on its
+    // move stream, the root receives on its move stream), while the kernels of round c + 1 are already queued behind
+    // them on the trace streams: the transfers hide behind the tracing.
+    rounds = (nPieces + G - 1) / G;
+    for (int c = 0; c < rounds; ++c) {
+        for (int k = c * G; k < nPieces && k < (c + 1) * G; ++k) {
+            Device &D = gDevices[owner[k]];
+            HIP_GO(hipSetDevice(D.id));
+            unsigned char *frame = owner[k] == 0 ? (unsigned char *)D.frame.ptr + (size_t)first[k] * nCols * pixelBytes
+                                                 : (unsigned char *)D.pieces.ptr + at[k] * nCols * pixelBytes;
+            int32_t *index = !hitIndexHost ? nullptr
+                           : owner[k] == 0 ? (int32_t *)D.index.ptr + (size_t)first[k] * nCols
+                                           : (int32_t *)D.pieceIndex.ptr + at[k] * nCols;
+            if ((rc = launchTrace(jobs[owner[k]], first[k], count[k], format, frame, index,
+                                  countersHost ? (GraftCounters *)D.counters.ptr : nullptr, D.stream)) != GRAFT_OK) goto done;
+            if (owner[k] != 0) {
+                HIP_GO(hipEventRecord(D.traced, D.stream));
+                HIP_GO(hipStreamWaitEvent(D.moveStream, D.traced, 0));
+            }
+        }
+        NCCL_TRY(gRccl.groupStart());
+        for (int k = c * G; k < nPieces && k < (c + 1) * G; ++k) {
+            if (owner[k] == 0) continue;
+            Device &D = gDevices[owner[k]];
+            const size_t bytes = (size_t)count[k] * nCols * pixelBytes;
+            NCCL_TRY(gRccl.send((unsigned char *)D.pieces.ptr + at[k] * nCols * pixelBytes, bytes, ncclChar, 0, D.comm, D.moveStream));
+            NCCL_TRY(gRccl.recv((unsigned char *)root.frame.ptr + (size_t)first[k] * nCols * pixelBytes, bytes, ncclChar, owner[k],
+                                root.comm, root.moveStream));
+            if (hitIndexHost) {
+                const size_t ib = (size_t)count[k] * nCols * 4;
+                NCCL_TRY(gRccl.send((int32_t *)D.pieceIndex.ptr + at[k] * nCols, ib, ncclChar, 0, D.comm, D.moveStream));
+                NCCL_TRY(gRccl.recv((int32_t *)root.index.ptr + (size_t)first[k] * nCols, ib, ncclChar, owner[k], root.comm, root.moveStream));
+            }
+        }
+        NCCL_TRY(gRccl.groupEnd());
+    }
+    // the assembled frame leaves the root once its own kernels and every transfer are done
+    for (int d = 0; d < G; ++d) {
+        HIP_GO(hipSetDevice(d));
+        HIP_GO(hipStreamSynchronize(gDevices[d].stream));
+        HIP_GO(hipStreamSynchronize(gDevices[d].moveStream));
+        if (countersHost) {
+            GraftCounters c = {0, 0};
+            HIP_GO(hipMemcpy(&c, gDevices[d].counters.ptr, sizeof c, hipMemcpyDeviceToHost));
+            sum.rays += c.rays;
+            sum.tests += c.tests;
+        }
+    }
+    HIP_GO(hipSetDevice(0));
+    HIP_GO(hipMemcpy(frameHost, root.frame.ptr, (size_t)nRows * nCols * pixelBytes, hipMemcpyDeviceToHost));
+    if (hitIndexHost) HIP_GO(hipMemcpy(hitIndexHost, root.index.ptr, (size_t)nRows * nCols * 4, hipMemcpyDeviceToHost));
+    if (countersHost) *countersHost = sum;
+done:
+    (void)hipSetDevice(0);
+    return rc;
 }
 
 static int probe(int which, const double *a, const double *b, double *out, size_t n) {

@@ -19,6 +19,11 @@
 #ifndef GRAFT_HEIGHT
 #define GRAFT_HEIGHT 512
 #endif
+/* GPUs to spread a frame over (one host thread drives them all): 1 unless the build says otherwise; never more than
+ * the machine has.  A 512 x 512 frame is far too small to gain from a second GPU; a 16384 x 16384 one is not. */
+#ifndef GRAFT_DEVICES
+#define GRAFT_DEVICES 1
+#endif
 
 /* The frame the GPU copies into: page-locked, kept from frame to frame (an interactive host traces one after every
  * key press, mainTracing.c:629-630), grown when the loop runs more iterations (513 per axis after zooming). */
@@ -51,7 +56,11 @@ void launchRays(void) {
     double *cols = NULL, *rows = NULL, *rgb = NULL;
     int nAvoid = 0, rc = GRAFT_OK;
 
-    if ((rc = graftInit(0)) != GRAFT_OK) goto done;
+    {
+        int devices = graftDeviceCount();
+        if (devices > GRAFT_DEVICES) devices = GRAFT_DEVICES;
+        if ((rc = graftInitDevices(devices < 1 ? 1 : devices)) != GRAFT_OK) goto done;
+    }
     graftCamInitialize(target, viewDir, targetToScreen, screenToCam, screenCenter, camPos); /* :388 */
 
     gs = calloc(numShapes > 0 ? numShapes : 1, sizeof *gs);
@@ -110,7 +119,7 @@ void launchRays(void) {
 
     rgb = frame_buffer(sizeof(double) * 3 * (size_t)view.nCols * view.nRows);
     if (!rgb) { rc = GRAFT_ERR_HIP; goto done; }
-    rc = graftRenderRows(&scene, &view, 0, view.nRows, GRAFT_OUT_F64_RGB, rgb, NULL, NULL);
+    rc = graftRenderFrameMulti(&scene, &view, GRAFT_OUT_F64_RGB, 8, rgb, NULL, NULL); /* one GPU: graftRenderRows */
     if (rc != GRAFT_OK) goto done;
 
     /* the display stays on the host: same calls, same order as :392-393, :422, :439 */

@@ -35,6 +35,23 @@ def init(device=0):
     _bound_device = device
 
 
+def init_devices(n):
+    """Bind GPUs 0..n-1 to this process (graftInitDevices); GPU 0 is the root and the device of the other calls."""
+    global _bound_device
+    check(lib.graftInitDevices(int(n)))
+    _bound_device = 0
+
+
+def frame_pieces(n_rows, n_devices, pieces_per_device):
+    """graftFramePieces: list of (first row, rows, owner device)."""
+    cap = lib.graftFramePieces(int(n_rows), int(n_devices), int(pieces_per_device), None, None, None, 0)
+    if cap < 0:
+        raise ValueError("bad frame or device count")
+    a, b, c = ((ctypes.c_int32 * max(cap, 1))() for _ in range(3))
+    lib.graftFramePieces(int(n_rows), int(n_devices), int(pieces_per_device), a, b, c, cap)
+    return [(a[i], b[i], c[i]) for i in range(cap)]
+
+
 def device_count():
     n = lib.graftDeviceCount()
     return max(n, 0)
@@ -434,6 +451,23 @@ class RayTracer:
                                   frame.ctypes.data_as(ctypes.c_void_p),
                                   index.ctypes.data_as(ctypes.c_void_p) if want_index else None,
                                   ctypes.byref(counters) if want_counters else None))
+        del keep
+        if want_counters:
+            self.last_counters = (counters.rays, counters.tests)
+        return (frame, index) if want_index else frame
+
+    def render_frame_multi(self, fmt=GRAFT_OUT_F64_RGB, pieces_per_device=8, want_index=False, want_counters=False):
+        """graftRenderFrameMulti: the whole frame over every GPU bound by init_devices(), assembled on GPU 0."""
+        self.camInitialize(self.target, self.targetToScreen, self.screenToCam)
+        scene, view, keep = self.pack()
+        dtype, ch = _FORMAT_DTYPE[fmt]
+        frame = np.zeros((view.nRows, view.nCols, ch), dtype=dtype)
+        index = np.full((view.nRows, view.nCols), -9, dtype=np.int32) if want_index else None
+        counters = GraftCounters() if want_counters else None
+        check(lib.graftRenderFrameMulti(ctypes.byref(scene), ctypes.byref(view), int(fmt), int(pieces_per_device),
+                                        frame.ctypes.data_as(ctypes.c_void_p),
+                                        index.ctypes.data_as(ctypes.c_void_p) if want_index else None,
+                                        ctypes.byref(counters) if want_counters else None))
         del keep
         if want_counters:
             self.last_counters = (counters.rays, counters.tests)

@@ -230,3 +230,20 @@ def test_render_rows_keeps_its_job_and_tables_between_calls(gpu):
     rt.lights[1].loc[1] += 10.0                       # a light moves: its table only
     check()
     assert get_diagnostic("table_builds") == built + 1 + 5 + 1
+
+
+def test_multi_device_entry_with_the_devices_present(gpu):
+    """graftInitDevices / graftRenderFrameMulti with every GPU this process can see (one on the test box, where the
+    call must be exactly graftRenderRows); more GPUs than present are refused."""
+    import raytracing_amd
+    from raytracing_amd import GraftError
+    n = raytracing_amd.device_count()
+    with pytest.raises(GraftError):
+        raytracing_amd.init_devices(n + 1)
+    raytracing_amd.init_devices(n)
+    rt = build("cfg5_128_depth4")
+    want = ob.render(rt, threads=THREADS, want_index=True, want_counters=True)
+    rgb, idx = rt.render_frame_multi(GRAFT_OUT_F64_RGB, 3, want_index=True, want_counters=True)
+    assert np.array_equal(idx, want["index"])
+    assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64))
+    assert rt.last_counters == want["counters"][:2]

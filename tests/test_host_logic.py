@@ -88,3 +88,17 @@ def test_write_ppm(tmp_path):
             assert np.array_equal(got, want32)
         else:
             assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("rows,world,chunks", [(16384, 8, 8), (8192, 4, 11), (4096, 2, 16), (512, 3, 5), (100, 8, 8),
+                                               (8, 8, 4), (1, 2, 3), (72, 5, 1), (4097, 7, 9)])
+def test_c_piece_list_equals_the_python_one(rows, world, chunks):
+    """graftFramePieces (what graftRenderFrameMulti deals to the GPUs of one process) against
+    raytracing_amd.distributed.frame_pieces (what the one-process-per-GPU path deals to the ranks)."""
+    from raytracing_amd import frame_pieces as c_pieces
+    from raytracing_amd.distributed import frame_pieces
+    got = c_pieces(rows, world, chunks)
+    assert got == frame_pieces(rows, world, chunks)
+    assert got[0][0] == 0 and sum(n for _, n, _ in got) == rows
+    for (a, n, _), (b, _, _) in zip(got, got[1:]):
+        assert a + n == b and a % 8 == 0
