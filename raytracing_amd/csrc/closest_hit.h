@@ -37,6 +37,9 @@ __device__ __forceinline__ void newPoint(const double start[3], const double dir
     out[2] = start[2] + scalar * dir[2];
 }
 
+__device__ __forceinline__ void exactSphere(const double *geom, int slot, int shape, double sx, double sy, double sz,
+                                            double dx, double dy, double dz, double &minDist, Hit &h);
+
 // rayIntersectAvoid (mainTracing.c:128-153) over sphereIntersect (shapes.c:47-73) and planeIntersect
 // (shapes.c:83-96).  Candidate normals are not formed here: only the winner's is used (mainTracing.c:146).
 template <int AVOID, bool LDSGEOM>
@@ -52,36 +55,30 @@ __device__ __forceinline__ void closestHit(const TraceParams &P, double sx, doub
     for (int r = 0; r < P.numRuns; ++r) {
         const DevRun run = P.runs[r];
         if (run.kind == GRAFT_SPHERE) {
-            const double *sp = geom + 4 * (size_t)run.slot;
-#pragma unroll 4
-            for (int j = 0; j < run.count; ++j) {
-                const double4v c4 = *(const double4v *)(sp + 4 * j);
-                const double cx = c4.x, cy = c4.y, cz = c4.z, rr = c4.w;
-                const double vx = sx - cx, vy = sy - cy, vz = sz - cz;
-                // vecDot's leading "0.0 +" only turns a -0 result into +0; it cannot change b*b or v.v
-                const double b = vx * dx + vy * dy + vz * dz;
-                const double vv = vx * vx + vy * vy + vz * vz;
-                const double disc = b * b - (vv - rr);
-                bool candidate = !(disc < 0);
-                if (AVOID == 1) candidate = candidate && (run.firstShape + j != avoidShape);
-                if (AVOID == 2) candidate = candidate && !(avoidRow && avoidRow[run.firstShape + j]);
-                if (candidate) {
-                    const double q = sqrt(disc);
-                    const double bz = b + 0.0;  // restores the +0 of the reference's dot product
-                    const double tFar = -bz + q;
-                    const double tNear = -bz - q;
-                    const double t = tNear >= 0 ? tNear : tFar;
-                    if (!(t < 0)) {
-                        const double lx = sx + t * dx, ly = sy + t * dy, lz = sz + t * dz;
-                        const double ex = lx - sx, ey = ly - sy, ez = lz - sz;
-                        const double dist = sqrt(dot3(ex, ey, ez, ex, ey, ez));
-                        if (minDist == -1 || dist < minDist) {
-                            minDist = dist;
-                            h.idx = run.firstShape + j;
-                            h.slot = run.slot + j;
-                            h.kind = GRAFT_SPHERE;
-                            h.x = lx; h.y = ly; h.z = lz;
-                        }
+            // Four spheres per trip (the geometry is followed by never-hit spheres of padding, and what is read past the
+            // end of a run is never used).  Per sphere the 16 operations of the discriminant b*b - (v.v - r*r) and
+            // nothing else: one integer test on the high words of four discriminants tells whether any of them is
+            // something other than a negative finite number (a discriminant is never -0: b*b is not), and only then are
+            // the four spheres gone through one by one, in index order.
+            const double4v *sp = (const double4v *)(geom + 4 * (size_t)run.slot);
+            for (int j = 0; j < run.count; j += 4) {
+                int top = (int)0x80000000;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double4v c = sp[j + u];
+                    const double vx = sx - c.x, vy = sy - c.y, vz = sz - c.z;
+                    // vecDot's leading "0.0 +" only turns a -0 result into +0; it cannot change b*b or v.v
+                    const double b = vx * dx + vy * dy + vz * dz;
+                    const double vv = vx * vx + vy * vy + vz * vz;
+                    top = max(top, __double2hiint(b * b - (vv - c.w)));
+                }
+                if (top >= (int)0xFFF00000) {  // not all four negative and finite
+#pragma nounroll
+                    for (int u = 0; u < 4; ++u) {
+                        bool candidate = j + u < run.count;
+                        if (AVOID == 1) candidate = candidate && (run.firstShape + j + u != avoidShape);
+                        if (AVOID == 2) candidate = candidate && !(avoidRow && avoidRow[run.firstShape + j + u]);
+                        if (candidate) exactSphere(geom, run.slot + j + u, run.firstShape + j + u, sx, sy, sz, dx, dy, dz, minDist, h);
                     }
                 }
             }

@@ -18,7 +18,7 @@ constexpr int kSmallBlock = 256;    // scenes whose geometry fits a quarter of t
 #define GRAFT_LARGE_BLOCK 1024
 #endif
 constexpr int kLargeBlock = GRAFT_LARGE_BLOCK;   // one workgroup per CU sharing up to the whole LDS
-constexpr int kGeomPad = 16;        // doubles of never-hit padding behind the packed geometry (the exact loop reads ahead)
+constexpr int kGeomPad = 32;        // doubles of never-hit padding behind the packed geometry (the exact loop reads ahead)
 constexpr int kCursors = 16;        // ticket counters of the many-counter kernels ...
 constexpr int kCursorStride = 32;   // ... one per 128-byte line
 constexpr size_t kLdsSmall = 36 * 1024;
