@@ -332,7 +332,19 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         const double lit = wDiff * light[c];
                         part[c] = lit + (amb + 0.0);
                     }
-                    if (mirror || glass) {  // children to trace: push this level
+                    if (mirror && !glass && depth + 1 >= P.maxDepth) {
+                        // The mirror child would return black at once (mainTracing.c:305-306) and there is no other
+                        // child: this level's value with the operations of :338, :363-369 on a black reflection,
+                        // without a trip through the stack.
+                        for (int c = 0; c < 3; ++c) {
+                            const double t = (1 - .5) * (1.0 - rgb[c]);  // mainTracing.c:334-336
+                            double mir = (rgb[c] + t) * 0.0;
+                            mir = wRefl * mir;
+                            const double out = mir + part[c];
+                            v[c] = (0.0 * 0.0) + out;
+                        }
+                        unwind = true;
+                    } else if (mirror || glass) {  // children to trace: push this level
                         double *lv = stk + kEntry * sp;
                         unsigned char fl = 0;
                         for (int c = 0; c < 3; ++c) {
