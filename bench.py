@@ -271,6 +271,20 @@ def host_threads():
     return n if n > 0 else len(os.sched_getaffinity(0))
 
 
+def rank_diagnostics(per_step, steps, local_rays, step_ms, world, dev):
+    """What every rank did per frame: its rays, the device time of its own kernels (first launch to last kernel done,
+    the transfers queued between them included), the host time spent waiting for transfers after the last kernel was
+    queued, and the whole step.  Collective: every rank calls it."""
+    mine = torch.tensor([local_rays,
+                         sum(d["trace_event"][0].elapsed_time(d["trace_event"][1]) for d in per_step) / steps,
+                         sum(d["wait_s"] for d in per_step) / steps * 1e3, step_ms,
+                         sum(d["pieces"] for d in per_step) / steps], dtype=torch.float64, device=dev)
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    return [{"rank": r, "rays": int(g[0]), "trace_ms": float(g[1]), "transfer_wait_ms": float(g[2]),
+             "step_ms": float(g[3]), "pieces": int(g[4])} for r, g in enumerate(gathered)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,18 +381,12 @@ def main():
     elapsed = float(t[0])
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
-    per_rank = None
+    per_rank, per_rank_error = None, None
     if world > 1:
-        # what every rank did per frame: its rays, the device time of its own kernels (first launch to last kernel
-        # done), the host time spent waiting for transfers after the last kernel was queued, and the whole step
-        mine = torch.tensor([local_rays,
-                             sum(d["trace_event"][0].elapsed_time(d["trace_event"][1]) for d in per_step) / args.steps,
-                             sum(d["wait_s"] for d in per_step) / args.steps * 1e3, kernel_ms,
-                             sum(d["pieces"] for d in per_step) / args.steps], dtype=torch.float64, device=dev)
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        per_rank = [{"rank": r, "rays": int(g[0]), "trace_ms": float(g[1]), "transfer_wait_ms": float(g[2]),
-                     "step_ms": float(g[3]), "pieces": int(g[4])} for r, g in enumerate(gathered)]
+        try:  # diagnostics only: whatever goes wrong here must not cost the run its result line
+            per_rank = rank_diagnostics(per_step, args.steps, local_rays, kernel_ms, world, dev)
+        except Exception as e:  # noqa: BLE001
+            per_rank_error = repr(e)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -402,9 +410,9 @@ def main():
             out["roofline"] = {"bound": "valu_fp64", "achieved": None, "peak": PEAK_FP64_VALU, "unit": "TFLOP/s",
                                "frac": None, "traffic": None, "kernel": "traceKernel",
                                "note": "see the 1-GPU line: at N > 1 a step is several launches per rank"}
-            mean_rays = rays / world
-            out["per_rank"] = per_rank
-            out["ray_imbalance"] = max(p["rays"] for p in per_rank) / mean_rays
+            out["per_rank"] = per_rank if per_rank is not None else {"error": per_rank_error}
+            if per_rank:
+                out["ray_imbalance"] = max(p["rays"] for p in per_rank) / (rays / world)
             torch.cuda.synchronize()
             # the assembled frame against rank 0's own trace of 64 tile rows spread over all pieces
             check = torch.empty((8, W, 4), dtype=torch.float32, device=dev)
