@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round-2 final measurements on the GPU box: counter records + kernel stats per workload, bench lines.
+set -e
+bash profiles/collect_all.sh r2f
+mkdir -p gpurun_out/r2_final
+timeout -k 10 600 python bench.py > gpurun_out/r2_final/bench_cfg4.json 2> gpurun_out/r2_final/bench_cfg4.err
+for wl in cfg3 cfg5; do
+  timeout -k 10 300 python bench.py --workload $wl --steps 10 --warmup 2 --no-frame512 > gpurun_out/r2_final/bench_$wl.json 2> gpurun_out/r2_final/bench_$wl.err
+done
+timeout -k 10 300 python bench.py --workload cfg3 --screen 0 --steps 10 --warmup 2 --no-frame512 --no-cpu > gpurun_out/r2_final/bench_cfg3_level0.json 2> gpurun_out/r2_final/bench_cfg3_level0.err
+timeout -k 10 300 python bench.py --workload default --steps 20 --warmup 2 --no-frame512 > gpurun_out/r2_final/bench_default.json 2> gpurun_out/r2_final/bench_default.err
+echo "final done"
