@@ -133,7 +133,6 @@ enum {
     GRAFT_DIAG_SCREEN_CAP = 0,       /* 0..5: highest screen level a job may use (graftJobScreenLevel); default 5 */
     GRAFT_DIAG_GROUP_SIZE = 1,       /* spheres per group of the two-level screens: 0 = chosen per scene, else 4..64, a multiple of 4 */
     GRAFT_DIAG_TILES_PER_TICKET = 2, /* 8x8 tiles a wave draws from the ticket counters at once: 0 = chosen per launch */
-    GRAFT_DIAG_DEFER_MIRRORS = 3,    /* 1 (default): mirror rays of grid-screened scenes are traced in launches of their own; 0: one launch */
     GRAFT_DIAG_TABLE_BUILDS = 4      /* read-only: screen tables built so far (shows what a re-render re-used) */
 };
 GRAFT_API int graftDiagnosticSet(int which, int value);

@@ -13,7 +13,7 @@ raytracing_amd.init(0)
 rt = scenes.workload(name, None, height)
 job = rt.create_job()
 frame = torch.empty((job.nRows, job.nCols, 4), dtype=torch.float32, device="cuda")
-cnt = torch.zeros(32, dtype=torch.int64, device="cuda")
+cnt = torch.zeros(16, dtype=torch.int64, device="cuda")
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 for _ in range(2):
     cnt.zero_()
@@ -34,9 +34,3 @@ if c[12]:
     print("   grid walk: %d calls (%.1f lanes each), %.1f loop iterations per call with %.1f lanes alive on average, "
           "%.0f cycles per call (%.1f%% of wave time), %.1f cycles per iteration"
           % (c[12], c[13] / c[12], c[10] / c[12], c[11] / max(c[10], 1), c[14] / c[12], 100.0 * c[14] / total, c[14] / max(c[10], 1)))
-for kind, base in (("closest", 16), ("shadow", 24)):
-    w = c[base:base + 8]
-    if w[0]:
-        print("   deferred %s walk: %d wave-steps with %.1f lanes alive; %d exact-test phases (%.2f per step) with %.1f lanes; "
-              "%d refill passes with %.1f idle lanes; %d trips of the outer loop"
-              % (kind, w[0], w[1] / w[0], w[2], w[2] / w[0], w[3] / max(w[2], 1), w[4], w[5] / max(w[4], 1), w[6]))

@@ -31,7 +31,6 @@
 #include "closest_hit.h"
 #include "pack_tables.h"
 #include "host_job.h"
-#include "deferred_mirror.h"
 
 using namespace graft;
 
@@ -55,9 +54,7 @@ namespace {
 // per-lane stack holds a tree walk (wider entries) instead of a chain.
 // MANYCURSORS: tickets come from kCursors counters instead of one (launches of cheap tiles, see below).  A
 // separate instantiation because the expensive-tile kernels lose 1-3 % to any change of this code (measured).
-// DEFER (SCREEN == 5 with a camera family, no anti-aliasing): a pixel whose first hit shoots a mirror ray that
-// has to be traced writes the ray down (deferred_mirror.h) and ends; later launches trace it and store the pixel.
-template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS, bool DEFER = false>
+template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
     if (LDSGEOM) {
         if (SCREEN >= 4) {
@@ -109,7 +106,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     if (mode == M_SHADOW) family = P.lightFamilyBase + li;
                     else if ((mode == M_INDEX || depth == 0) && P.cameraFamily >= 0) family = P.cameraFamily;
                     // level 5: only the coherent rays of a pixel's first level walk the families' tables
-                    if (SCREEN == 5 && !DEFER && (depth > 0 || family < 0))
+                    if (SCREEN == 5 && (depth > 0 || family < 0))
                         closestHitGrid<AVOID>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, negThreshold, tLimit, h);
                     else
                         closestHitFamilies<AVOID, EXACTLDS, SCREEN >= 4, SCREEN != 5>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, family, negThreshold, h);
@@ -184,7 +181,6 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         const ConstDoubles cam = cameraView(P);
         double acc[3] = {cam[CAM_BACKGROUND], cam[CAM_BACKGROUND + 1], cam[CAM_BACKGROUND + 2]};  // mainTracing.c:395
         int firstIdx = -1;
-        unsigned deferredPixel = kNoTask;  // DEFER: the pixel, when its value comes from the launches that follow
         if (inside) {
             const double colI = P.colOff[ix], rowJ = P.rowOff[iy];
             const size_t pixel = (size_t)by * P.nCols + ix;
@@ -336,20 +332,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         const double lit = wDiff * light[c];
                         part[c] = lit + (amb + 0.0);
                     }
-                    if (DEFER && mirror && depth + 1 < P.maxDepth) {  // reflection(), mainTracing.c:180-190, written down
-                        const double k2 = 2 * dot3(din[0], din[1], din[2], nrm[0], nrm[1], nrm[2]);
-                        double rx = din[0] - k2 * nrm[0], ry = din[1] - k2 * nrm[1], rz = din[2] - k2 * nrm[2];
-                        unit3(rx, ry, rz, rx, ry, rz);
-                        MirrorRecord *r = (MirrorRecord *)P.mirrorRecords + pixel;
-                        r->d[0] = rx; r->d[1] = ry; r->d[2] = rz;
-                        r->o[0] = loc[0] + .000001 * rx;
-                        r->o[1] = loc[1] + .000001 * ry;
-                        r->o[2] = loc[2] + .000001 * rz;
-                        r->litW = litW;
-                        r->shapeLight = (unsigned)hitIdx | (unsigned)(litLight + 1) << 24;
-                        deferredPixel = (unsigned)pixel;
-                        mode = M_DONE;
-                    } else if (mirror && !glass && depth + 1 >= P.maxDepth) {
+                    if (mirror && !glass && depth + 1 >= P.maxDepth) {
                         // The mirror child would return black at once (mainTracing.c:305-306) and there is no other
                         // child: this level's value with the operations of :338, :363-369 on a black reflection,
                         // without a trip through the stack.
@@ -361,7 +344,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                             v[c] = (0.0 * 0.0) + out;
                         }
                         unwind = true;
-                    } else if (!DEFER && (mirror || glass)) {  // children to trace: push this level
+                    } else if (mirror || glass) {  // children to trace: push this level
                         double *lv = stk + kEntry * sp;
                         unsigned char fl = 0;
                         for (int c = 0; c < 3; ++c) {
@@ -472,9 +455,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 acc[0] = acc[0] / n; acc[1] = acc[1] / n; acc[2] = acc[2] / n;
             }
             if (P.hitIndex) P.hitIndex[pixel] = firstIdx;
-            if (!DEFER || deferredPixel == kNoTask) storeColor(pixel, acc);
+            storeColor(pixel, acc);
         }
-        if (DEFER) P.mirrorCand[(size_t)tile * 64 + lane] = deferredPixel;
         ++tile;
     }
     if (P.counters) {
@@ -554,7 +536,6 @@ struct Reusable {
 
 constexpr int kMaxDevices = 16;
 constexpr size_t kScratchBytes = (size_t)4 << 20;  // device block of graftRenderRowsNoAlloc: tables + ticket counters
-constexpr size_t kDeferBudget = (size_t)48 << 30;  // most a job's deferred-mirror records may take; beyond: one launch
 
 // What the library holds per GPU.
 struct Device {
@@ -608,7 +589,6 @@ void readSettingsOnce() {
         if (e[0] >= '0' && e[0] <= '5' && !e[1]) gSettings.screenCap = e[0] - '0';
     if (const char *e = getenv("GRAFT_GROUP")) gSettings.groupSize = atoi(e);
     if (const char *e = getenv("GRAFT_PER_TICKET")) gSettings.tilesPerTicket = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char *e = getenv("GRAFT_DEFER")) gSettings.deferMirrors = atoi(e) ? 1 : 0;
 }
 
 typedef void (*TraceFn)(const TraceParams);
@@ -636,22 +616,6 @@ TraceFn pickKernelM(int avoidMode, bool lds, int screen, bool exactLds, bool tra
          : avoidMode == 1 ? pickKernelA<1, M>(lds, screen, exactLds) : pickKernelA<2, M>(lds, screen, exactLds);
 }
 
-// first-level kernel of the deferred-mirror path (screen level 5, tables in LDS, nothing transparent)
-TraceFn pickDeferKernel(int avoidMode, bool manyCursors) {
-    if (manyCursors)
-        return avoidMode == 0 ? traceKernel<0, true, 5, false, false, true, true>
-             : avoidMode == 1 ? traceKernel<1, true, 5, false, false, true, true> : traceKernel<2, true, 5, false, false, true, true>;
-    return avoidMode == 0 ? traceKernel<0, true, 5, false, false, false, true>
-         : avoidMode == 1 ? traceKernel<1, true, 5, false, false, false, true> : traceKernel<2, true, 5, false, false, false, true>;
-}
-
-typedef void (*WalkFn)(const TraceParams, const MirrorQueue);
-
-WalkFn pickWalkKernel(int avoidMode, bool shadow) {
-    if (!shadow) return mirrorWalkKernel<0, false>;  // avoid lists only concern shadow rays (mainTracing.c:205)
-    return avoidMode == 0 ? mirrorWalkKernel<0, true> : avoidMode == 1 ? mirrorWalkKernel<1, true> : mirrorWalkKernel<2, true>;
-}
-
 TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool manyCursors) {
     return manyCursors ? pickKernelM<true>(avoidMode, lds, screen, exactLds, transp)
                        : pickKernelM<false>(avoidMode, lds, screen, exactLds, transp);
@@ -674,9 +638,6 @@ struct GraftJob {
     void *arena;      // the device block holding every table
     bool ownsArena;   // false: the block belongs to a Device (graftRenderRows' cached job)
     Device *dev;
-    bool mayAllocate = true;  // false: traces of this job must not allocate (graftRenderRowsNoAlloc)
-    Reusable mirrorQueue;     // deferred-mirror path: records, hits and counters, sized by the largest band traced so far
-    ~GraftJob() { mirrorQueue.release(); }
 };
 
 namespace {
@@ -768,42 +729,7 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     // cheap tiles (few samples per pixel) are drawn several at a time and from several counters
     const int samples = P.aliasing ? P.numPasses * P.numPasses : 1;
     const bool manyCursors = samples < 4;
-    // Mirror rays of large scenes go through launches of their own (deferred_mirror.h) when the job has the grid, a
-    // camera family for the first level, one sample per pixel, and the memory for the records can be had.
-    MirrorQueue Q;
-    memset(&Q, 0, sizeof Q);
-    bool defer = gSettings.deferMirrors != 0 && job->mayAllocate && job->screen == 5 && job->lds && job->mirrors &&
-                 !job->transp && P.maxDepth >= 2 && !P.aliasing && P.cameraFamily >= 0;
-    if (defer) {
-        const size_t cap = (size_t)P.nCols * nRows;
-        const size_t levels = (size_t)P.maxDepth - 1;
-        const size_t nCand = 64 * (size_t)tiles;  // (>= cap)
-        const size_t oHits = sizeof(MirrorRecord) * cap * levels;
-        const size_t oCand = oHits + sizeof(MirrorHit) * cap;
-        const size_t oActive = oCand + sizeof(unsigned) * nCand;
-        const size_t oList = oActive + sizeof(unsigned) * cap;
-        const size_t oLit = oList + sizeof(unsigned) * cap;
-        const size_t oCounts = (oLit + (size_t)P.numLights * cap + 255) & ~(size_t)255;
-        const size_t bytes = oCounts + sizeof(unsigned) * kCountsPerLevel * (kMaxDepth + 1);
-        if (nCand >= 0x7ffffff0u || bytes > kDeferBudget || job->mirrorQueue.reserve(bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            defer = false;
-        } else {
-            unsigned char *b = (unsigned char *)job->mirrorQueue.ptr;
-            Q.records = (MirrorRecord *)b;
-            Q.hits = (MirrorHit *)(b + oHits);
-            Q.cand = (unsigned *)(b + oCand);
-            Q.active = (unsigned *)(b + oActive);
-            Q.hitList = (unsigned *)(b + oList);
-            Q.lit = b + oLit;
-            Q.counts = (unsigned *)(b + oCounts);
-            Q.cap = (unsigned)cap;
-            P.mirrorRecords = Q.records;
-            P.mirrorCand = Q.cand;
-        }
-    }
-    TraceFn fn = defer ? pickDeferKernel(job->avoidMode, manyCursors)
-                       : pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, manyCursors);
+    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, manyCursors);
     if (job->lds && std::find(D->configured.begin(), D->configured.end(), (const void *)fn) == D->configured.end()) {
         // more dynamic LDS than the default limit: raised once per kernel and device, when the kernel is first used
         HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
@@ -829,35 +755,8 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     P.prefetchTickets = (tiles + perTicket - 1) / perTicket >= 8 * waves ? 1 : 0;
     if (manyCursors) HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int) * kCursors * kCursorStride, s));
     else HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)P.tileCursor, grid * wavesPerBlock, 1, s));
-    if (defer) HIP_TRY(hipMemsetAsync(Q.counts, 0, sizeof(unsigned) * kCountsPerLevel * (kMaxDepth + 1), s));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(job->block), job->ldsBytes, s, P);
     HIP_TRY(hipGetLastError());
-    if (defer) {
-        // per level of the recursion: closest hits of the level's mirror rays, light visibility of those hits, shading
-        // (which writes the next level's rays).  How many there are is only known on the device: every launch is
-        // sized for the machine and reads its list's length itself.
-        WalkFn walks[2] = {pickWalkKernel(job->avoidMode, false), pickWalkKernel(job->avoidMode, true)};
-        for (WalkFn w : walks)
-            if (std::find(D->configured.begin(), D->configured.end(), (const void *)w) == D->configured.end()) {
-                HIP_TRY(hipFuncSetAttribute((const void *)w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
-                D->configured.push_back((const void *)w);
-            }
-        const dim3 small(D->numCU * 8), walkers(D->numCU);
-        hipLaunchKernelGGL(mirrorCompactKernel, small, dim3(256), 0, s, Q.cand, (unsigned)(64 * tiles), nullptr, Q.active,
-                           Q.counts + kCountsPerLevel + MQ_RECORDS);
-        for (int level = 1; level < P.maxDepth; ++level) {
-            Q.level = level;
-            unsigned *counts = Q.counts + kCountsPerLevel * level;
-            hipLaunchKernelGGL(walks[0], walkers, dim3(kLargeBlock), job->ldsBytes, s, P, Q);
-            hipLaunchKernelGGL(mirrorCompactKernel, small, dim3(256), 0, s, Q.cand, 0u, counts + MQ_RECORDS, Q.hitList, counts + MQ_HITS);
-            if (P.numLights > 0) hipLaunchKernelGGL(walks[1], walkers, dim3(kLargeBlock), job->ldsBytes, s, P, Q);
-            hipLaunchKernelGGL(mirrorShadeKernel, small, dim3(256), 0, s, P, Q);
-            if (level + 1 < P.maxDepth)
-                hipLaunchKernelGGL(mirrorCompactKernel, small, dim3(256), 0, s, Q.cand, 0u, counts + MQ_HITS, Q.active,
-                                   counts + kCountsPerLevel + MQ_RECORDS);
-            HIP_TRY(hipGetLastError());
-        }
-    }
     return GRAFT_OK;
 }
 
@@ -916,9 +815,6 @@ GRAFT_API int graftDiagnosticSet(int which, int value) {
             if (value < 0) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: tiles per ticket %d", value);
             gSettings.tilesPerTicket = value;
             return GRAFT_OK;
-        case GRAFT_DIAG_DEFER_MIRRORS:
-            gSettings.deferMirrors = value ? 1 : 0;
-            return GRAFT_OK;
         default:
             return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: unknown setting %d", which);
     }
@@ -930,7 +826,6 @@ GRAFT_API int graftDiagnosticGet(int which) {
         case GRAFT_DIAG_SCREEN_CAP: return gSettings.screenCap;
         case GRAFT_DIAG_GROUP_SIZE: return gSettings.groupSize;
         case GRAFT_DIAG_TILES_PER_TICKET: return gSettings.tilesPerTicket;
-        case GRAFT_DIAG_DEFER_MIRRORS: return gSettings.deferMirrors;
         case GRAFT_DIAG_TABLE_BUILDS: return (int)(gTables.builds & 0x7fffffff);
         default: return -1;
     }
@@ -1145,7 +1040,6 @@ GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *v
                     "scratch block holds %zu (use graftRenderRows or graftJobCreate)", J.image.size(), kScratchBytes);
     GraftJob job;
     describe(&job, J, D->scratch, false, D);
-    job.mayAllocate = false;
     rc = checkTraceArgs("graftRenderRowsNoAlloc", &job, row0, nRows, format, frameDevice);
     if (rc != GRAFT_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : D->stream;

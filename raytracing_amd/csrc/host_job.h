@@ -22,7 +22,6 @@ struct Settings {
     int screenCap = 5;       // highest screen level a job may use
     int groupSize = 0;       // spheres per group of the two-level screens, 0 = chosen per scene
     int tilesPerTicket = 0;  // tiles a wave draws at once, 0 = chosen per launch
-    int deferMirrors = 1;    // mirror rays of grid scenes in launches of their own (deferred_mirror.h); 0 = one launch
 };
 
 struct PackedJob {

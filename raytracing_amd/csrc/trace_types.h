@@ -113,9 +113,6 @@ struct TraceParams {
     int *hitIndex;
     unsigned long long *counters;  // {rays, tests} or null
     int *tileCursor;
-    // first-level kernel of the deferred-mirror path: level-1 records by pixel, candidate per (tile, lane) (deferred_mirror.h)
-    void *mirrorRecords;
-    unsigned *mirrorCand;
 };
 
 extern __shared__ __attribute__((aligned(32))) double ldsGeom[];
