@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 closestHit<AVOID, false>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
             }
         } else {
-            closestHit<AVOID, LDSGEOM>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
+            closestHit<AVOID, LDSGEOM, true>(P, o[0], o[1], o[2], d[0], d[1], d[2], avoidShape, avoidRow, h);
         }
         return avoided;
     };

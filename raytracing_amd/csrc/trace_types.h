@@ -81,6 +81,7 @@ struct TraceParams {
     int tilesPerTicket;        // consecutive tiles a wave takes per draw from a counter
     int prefetchTickets;       // draw the next ticket one ticket ahead (plenty of tickets per wave)
     int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
+    int fusedMiss;             // no sphere has a squared radius below 1e-280: the exact loop may prove misses with FMAs
     int format;
     int filterFloats;          // floats of the single-precision screen table staged in LDS, 0 = no screen
     int groupEntries;          // grouped screen: entries of the group table (multiple of 8), 0 = not grouped

@@ -127,6 +127,24 @@ def test_tiny_giant_and_far_spheres(gpu):
     check_all_levels(rt)
 
 
+def test_vanishing_radii(gpu):
+    """Squared radii in and below the denormal range (and zero): the exact loop's fused miss test is switched off for
+    such a job; a camera inside a sphere and a sphere centred on a light keep the test's "inside" side busy."""
+    rt = scene(41, 60)
+    rt.sphereSetup(1e-150, [5, -3, 60], 60, [1, 1, 1], 0.0, 0.1, 1.0, 0.0)
+    rt.sphereSetup(0.0, [-20, 12, 80], 61, [1, 1, 1], 0.0, 0.1, 1.0, 0.0)
+    rt.sphereSetup(3e-162, [30, 30, 30], 62, [1, 1, 1], 0.3, 0.1, 1.0, 0.0)
+    rt.numShapes = 63
+    check_all_levels(rt, levels=(0, 1, 3))
+    rt = scene(42, 60)
+    rt.camInitialize(rt.target, rt.targetToScreen, rt.screenToCam)
+    cam, L = rt.camPos, rt.lights[0].loc
+    rt.sphereSetup(2000.0, [cam[0] + 3, cam[1] - 2, cam[2] + 100], 60, [.4, .6, .9], 0.2, 0.1, 1.0, 0.0)
+    rt.sphereSetup(25.0, [L[0], L[1], L[2]], 61, [.9, .9, .2], 0.0, 0.1, 1.0, 0.0)
+    rt.numShapes = 62
+    check_all_levels(rt, levels=(0, 1, 3))
+
+
 def test_large_coordinates_fall_back(gpu):
     """Coordinates beyond 1e5 disable the two-level screens, beyond 1e15 the per-sphere screen; results stay exact."""
     rt = scene(17, 100, centre=(3e5, -2e5, 1e5), box=300.0)
