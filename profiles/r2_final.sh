@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 final measurements on the GPU box: counter records + kernel stats per workload, bench lines.
 set -e
-bash profiles/collect_all.sh r2f
+# (counter records first: bash profiles/collect_all.sh <tag>, then profiles/summarize_pmc.py per workload, so that the bench lines find records of this build)
 mkdir -p gpurun_out/r2_final
 timeout -k 10 600 python bench.py > gpurun_out/r2_final/bench_cfg4.json 2> gpurun_out/r2_final/bench_cfg4.err
 for wl in cfg3 cfg5; do
