@@ -9,7 +9,9 @@ N > 1 the rows are dealt to the ranks in pieces and every piece is sent to rank 
 is being traced.  Prints ONE JSON line on rank 0.
 
 metric  Mrays/s, ray = one closest-hit query (primary + shadow + reflection; rayIntersectAvoid of the
-        reference, mainTracing.c:128), counted by the kernel itself in an untimed pass.
+        reference, mainTracing.c:128) that the library MADE, counted by the kernel itself in an untimed pass.  The
+        reference makes more of them for the same frame (shadow rays whose answer its lighting() overwrites); that
+        count and the rate it would give are under `reference`, the frame time is ms_per_step.
 roofline  the trace kernel is bound by the vector ALU.  achieved = FP64 flop the kernel EXECUTED per launch (hardware
         counters of the same command, kept under profiles/ because counters cannot be read in-process:
         (ADD + MUL + 2 FMA + TRANS wave-instructions) x 64 lanes) / mean kernel time measured here (HIP events on the
@@ -91,6 +93,7 @@ def cpu_baseline(rt, gpu_band, row0, n_rows, cores, budget_rows):
         rays1 += o["counters"][0]
     return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%d of %d rows of the same frame (evenly spaced), %.1f s of CPU work" % (len(picks), rt.HEIGHT, secs),
+            "whole_frame_s_extrapolated": secs * n_rows / len(picks),
             "sample_matches_gpu": bool(exact),
             "single_core_value": rays1 / secs1 / 1e6, "single_core_sample": "%d of those rows, %.1f s" % (len(few), secs1)}
 
@@ -333,7 +336,7 @@ def main():
     else:          # the other ranks trace their pieces into a buffer of their own and send them to rank 0
         frame = None
         band = torch.empty((local_rows(H, world, rank, args.chunks), W, 4), dtype=torch.float32, device=dev)
-    counters = torch.zeros(2, dtype=torch.int64, device=dev)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)  # one GraftCounters
     # a real (non-null) stream: kernels, events and the RCCL transfers of the gather are all ordered on it
     torch_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(torch_stream)
@@ -357,8 +360,9 @@ def main():
     stats = counters.clone()
     if world > 1:
         dist.all_reduce(stats)
-    rays, tests = int(stats[0]), int(stats[1])
-    local_rays, local_tests = int(counters[0]), int(counters[1])
+    # stats: GraftCounters = the reference's queries and tests for this frame, and the queries the library made
+    ref_rays, tests, rays = int(stats[0]), int(stats[1]), int(stats[2])
+    local_rays, local_tests = int(counters[2]), int(counters[1])
 
     for _ in range(args.warmup):
         step()
@@ -403,6 +407,14 @@ def main():
                                                             "RCCL send/recv to rank 0 pipelined behind tracing"
                                                             % (args.chunks, world))},
             "rays_per_frame": rays, "tests_per_frame": tests,
+            "reference": {"rays_per_frame": ref_rays,
+                          "equivalent_Mrays_per_s": ref_rays / (elapsed / args.steps) / 1e6,
+                          "note": "closest-hit queries the reference makes for this frame.  `value` counts the "
+                                  "queries the library made: per shaded hit it asks the lights last to first and "
+                                  "stops at the first unshadowed one, because the reference's lighting() lets every "
+                                  "unshadowed light overwrite the one before (mainTracing.c:223-225); frames are "
+                                  "bit-identical, and tests_per_frame (the roofline's algorithmic count) is the "
+                                  "reference's"},
             "primary_Msamples_per_s": W * H * (rt.numPasses ** 2 if rt.aliasing else 1) / (elapsed / args.steps) / 1e6,
             "kernel_source_hash": kernel_source_hash(),
         }

@@ -97,11 +97,16 @@ typedef struct GraftView {
     const double *rowOffsets;
 } GraftView;
 
-/* Ray statistics of a trace: closest-hit queries (one per rayIntersectAvoid call, mainTracing.c:128:
- * primary + shadow + reflection) and ray-shape evaluations (one per shapes[k]->intersection call, :139). */
+/* Ray statistics of a trace.  `rays`, `tests`: what the REFERENCE does for these pixels -- closest-hit queries (one
+ * per rayIntersectAvoid call, mainTracing.c:128: primary + shadow + reflection) and ray-shape evaluations (one per
+ * shapes[k]->intersection call, :139).  `raysTraced`: the closest-hit queries the library made.  It makes fewer:
+ * lighting() (:196-229) lets every unshadowed light overwrite the one before, so the library asks the lights last
+ * to first and stops at the first unshadowed one; the shadow rays of the lights before it are never shot. */
 typedef struct GraftCounters {
     uint64_t rays;
     uint64_t tests;
+    uint64_t raysTraced;
+    uint64_t reserved;
 } GraftCounters;
 
 typedef struct GraftJob GraftJob; /* a scene + view packed and resident in device memory */

@@ -132,14 +132,14 @@ class Prepared:
 
 
 def render(st, row0=0, n_rows=None, threads=1, want_rgb=True, want_index=False, want_counters=False):
-    """Loop rows [row0,row0+n_rows) -> dict(rgb=[rows][nCols][3], index=[rows][nCols], counters=(rays,tests,shoots))."""
+    """Loop rows [row0,row0+n_rows) -> dict(rgb=[rows][nCols][3], index=[rows][nCols], counters=(rays,tests,shoots,overwritten shadow rays))."""
     pr = Prepared(st)
     J = pr.job
     if n_rows is None:
         n_rows = J.nRows - row0
     rgb = np.zeros((n_rows, J.nCols, 3)) if want_rgb else None
     index = np.full((n_rows, J.nCols), -9, dtype=np.int32) if want_index else None
-    cnt = np.zeros(3, dtype=np.uint64) if want_counters else None
+    cnt = np.zeros(4, dtype=np.uint64) if want_counters else None
     rc = lib().oracle_render(ctypes.byref(J), int(row0), int(row0 + n_rows), int(threads),
                              rgb.ctypes.data_as(ctypes.c_void_p) if want_rgb else None,
                              index.ctypes.data_as(ctypes.c_void_p) if want_index else None,

@@ -59,7 +59,9 @@ typedef struct OracleJob {
     const double *rowOff;   /* the values j takes, in order */
 } OracleJob;
 
-typedef struct Counters { uint64_t rays, tests, shoots; } Counters;
+/* overwritten: shadow rays of lights that come before the last unshadowed light of their hit -- queries whose
+ * answers mainTracing.c:223-225 overwrites (the product does not make them and reports how many it made) */
+typedef struct Counters { uint64_t rays, tests, shoots, overwritten; } Counters;
 
 /* ---- vector.c ---- */
 static inline void v3copy(const double v[3], double out[3]) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; } /* vector.c:18 */
@@ -179,6 +181,7 @@ static int shoot(const OracleJob *J, const double s[3], const double d[3], doubl
 /* mainTracing.c:196-229: the last light that is not shadowed overwrites the result */
 static void diffuse(const OracleJob *J, const double loc[3], const double normal[3], const double surf[3],
                     double rgb[3], Counters *C) {
+    int lastLit = -1;
     for (int i = 0; i < J->numLights; ++i) {
         const double *lloc = J->lightLoc + 3 * i, *lcol = J->lightColor + 3 * i;
         double toLight[3], dir[3] = {0, 0, 0}, origin[3], tiny[3];
@@ -196,6 +199,7 @@ static void diffuse(const OracleJob *J, const double loc[3], const double normal
             lit = v3dot(back, dir) < 0.1;
         }
         if (lit) {
+            lastLit = i;
             double l[3];
             v3sub(lloc, loc, l);
             v3unit(l, l);
@@ -206,6 +210,7 @@ static void diffuse(const OracleJob *J, const double loc[3], const double normal
             v3copy(c, rgb);
         }
     }
+    if (lastLit > 0) C->overwritten += (uint64_t)lastLit;
 }
 
 /* mainTracing.c:232-270, bug for bug: the POSITION s (not the direction d) is scaled by eta and used both in
@@ -408,7 +413,8 @@ static void *chunkWorker(void *arg) {
  * Trace loop rows [row0,row1) of the frame.  rgb (optional) receives what the reference hands to pixSetRGB
  * for loop indices (ix,iy), laid out [iy-row0][ix][3]; index (optional) receives the closest-shape index
  * (-1 = miss) of the anti-aliasing-off primary ray of each pixel (mainTracing.c:425-437 + :157).
- * counters (optional, 3 words) receive: closest-hit queries, ray-shape evaluations, shootRay calls made for rgb.
+ * counters (optional, 4 words) receive: closest-hit queries, ray-shape evaluations, shootRay calls made for rgb,
+ * and how many of the queries were shadow rays whose answer a later light overwrote.
  * Work is handed to `threads` threads in pieces of 32 pixels of one row (pixels are independent).
  * Returns 0.
  */
@@ -428,9 +434,10 @@ int oracle_render(const OracleJob *J, int row0, int row1, int threads, double *r
         for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
     }
     if (counters) {
-        counters[0] = counters[1] = counters[2] = 0;
+        counters[0] = counters[1] = counters[2] = counters[3] = 0;
         for (int t = 0; t < threads; ++t) {
             counters[0] += w[t].C.rays; counters[1] += w[t].C.tests; counters[2] += w[t].C.shoots;
+            counters[3] += w[t].C.overwritten;
         }
     }
     free(w); free(tid);

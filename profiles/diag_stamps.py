@@ -13,14 +13,17 @@ raytracing_amd.init(0)
 rt = scenes.workload(name, None, height)
 job = rt.create_job()
 frame = torch.empty((job.nRows, job.nCols, 4), dtype=torch.float32, device="cuda")
-cnt = torch.zeros(16, dtype=torch.int64, device="cuda")
+cnt = torch.zeros(24, dtype=torch.int64, device="cuda")
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 for _ in range(2):
     cnt.zero_()
     job.trace(0, job.nRows, GRAFT_OUT_F32_RGBA, frame.data_ptr(), None, cnt.data_ptr(), st.cuda_stream)
     torch.cuda.synchronize()
 c = cnt.tolist()
-rays, tests, total, hit, rounds, waves, loop = c[:7]
+rays, tests, traced = c[:3]
+total, hit, rounds, waves, loop = c[4:9]
+rays = traced  # lanes busy per round: the queries really made
+c = c[:2] + c[4:]  # (the indices below are those of the stamp counters, which start behind GraftCounters)
 tiles = ((job.nCols + 7) // 8) * ((job.nRows + 7) // 8)
 print("%s: waves %d, tiles %d, wave-rounds %d (%.1f lanes busy per round), cycles per wave %.3g | shares of wave time: "
       "closest-hit %.1f%%, rest of the ray loop %.1f%%, outside the loop (tile set-up, ticket, store) %.1f%% | per round: "

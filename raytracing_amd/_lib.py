@@ -49,7 +49,8 @@ class GraftView(ctypes.Structure):
 
 
 class GraftCounters(ctypes.Structure):
-    _fields_ = [("rays", ctypes.c_uint64), ("tests", ctypes.c_uint64)]
+    _fields_ = [("rays", ctypes.c_uint64), ("tests", ctypes.c_uint64), ("raysTraced", ctypes.c_uint64),
+                ("reserved", ctypes.c_uint64)]
 
 
 class GraftError(RuntimeError):

@@ -388,7 +388,7 @@ __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double s
                     if (AVOID == 1) skip = skip || shape == avoidShape;
                     if (AVOID == 2) skip = skip || (avoidRow && shape >= 0 && avoidRow[shape]);
 #ifdef GRAFT_STAMPS
-                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 10, 1ull);
 #endif
                     if (!skip) exactSphereLazy(geom, shape, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
                 }
@@ -405,7 +405,7 @@ __device__ __forceinline__ void closestHitGrouped(const TraceParams &P, double s
                 const float eu = u == 0 ? e0 : u == 1 ? e1 : u == 2 ? e2 : e3;
                 if (!(eu < negThreshold)) {
 #ifdef GRAFT_STAMPS
-                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 9, 1ull);
 #endif
                     const int m0 = (j + u) * P.groupSize;
 #pragma nounroll
@@ -493,7 +493,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                         if (AVOID == 1) skip = skip || shape == avoidShape;
                         if (AVOID == 2) skip = skip || (avoidRow && shape >= 0 && avoidRow[shape]);
 #ifdef GRAFT_STAMPS
-                        if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
+                        if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 10, 1ull);
 #endif
                         if (!skip) exactSphereLazy(geom, shape, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
                     }
@@ -510,7 +510,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                     const float eu = u == 0 ? e0 : u == 1 ? e1 : u == 2 ? e2 : e3;
                     if (!(eu < limit)) {
 #ifdef GRAFT_STAMPS
-                        if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
+                        if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 9, 1ull);
 #endif
                         if (!SUPER) {
                             const int m0 = (j + u) * P.groupSize;
@@ -545,7 +545,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
             auto flush = [&]() {
                 if (pending >= 0) {
 #ifdef GRAFT_STAMPS
-                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 10, 1ull);
 #endif
                     exactSphereLazy(geom, pending, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
                     pending = -1;
@@ -583,7 +583,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                         const bool inGroup = inSuper && !(eu < limit);
                         if (__ballot(inGroup)) {
 #ifdef GRAFT_STAMPS
-                            if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 7, 1ull);
+                            if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 9, 1ull);
 #endif
                             if (CONE) {
                                 const int m0 = (j + u) * P.groupSize;
@@ -612,7 +612,7 @@ __device__ __forceinline__ void closestHitFamilies(const TraceParams &P, double 
                         const bool inSuper = !(eu < limit);
                         if (__ballot(inSuper)) {
 #ifdef GRAFT_STAMPS
-                            if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 9, 1ull);
+                            if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 11, 1ull);
 #endif
 #pragma nounroll
                             for (int half = 0; half < 2; ++half) {
@@ -764,14 +764,14 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
 #ifdef GRAFT_STAMPS  // diagnostic build: calls, iterations of the loop below, lanes alive in them, rounds of exact tests
     const unsigned long long stampOn = __ballot(1);
     const bool stampLeader = lane64() == (int)__builtin_ctzll(stampOn);
-    if (P.counters && stampLeader) { atomicAdd(P.counters + 12, 1ull); atomicAdd(P.counters + 13, (unsigned long long)__popcll(stampOn)); }
+    if (P.counters && stampLeader) { atomicAdd(P.counters + 14, 1ull); atomicAdd(P.counters + 15, (unsigned long long)__popcll(stampOn)); }
     const unsigned long long stampGrid0 = clock64();
 #endif
     while (alive) {
 #ifdef GRAFT_STAMPS
         if (P.counters) {
             const unsigned long long on = __ballot(1);
-            if (lane64() == (int)__builtin_ctzll(on)) { atomicAdd(P.counters + 10, 1ull); atomicAdd(P.counters + 11, (unsigned long long)__popcll(on)); }
+            if (lane64() == (int)__builtin_ctzll(on)) { atomicAdd(P.counters + 12, 1ull); atomicAdd(P.counters + 13, (unsigned long long)__popcll(on)); }
         }
 #endif
         // Up to two entries of the lane's cell through the screen, without branches (the entry list is padded, so the
@@ -795,7 +795,7 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
             for (int trip = 0; trip < 3; ++trip) {
                 if (__ballot(pending >= 0 && (c0 >= 0 || cellDone))) {
 #ifdef GRAFT_STAMPS
-                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 8, 1ull);
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 10, 1ull);
 #endif
                     if (pending >= 0) {
                         exactSphereLazy(pendingGeom, pending, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
@@ -835,7 +835,7 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
         }
     }
 #ifdef GRAFT_STAMPS
-    if (P.counters && stampLeader) atomicAdd(P.counters + 14, (unsigned long long)(clock64() - stampGrid0));
+    if (P.counters && stampLeader) atomicAdd(P.counters + 16, (unsigned long long)(clock64() - stampGrid0));
 #endif
     finishBest(closest, sx, sy, sz, dx, dy, dz, h);
 }

@@ -77,7 +77,9 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     const int lane = threadIdx.x & 63;
     const int lx = lane & (kTile - 1), ly = lane >> 3;
     const int nSamples = P.aliasing ? P.numPasses * P.numPasses : 1;
-    unsigned long long rayCount = 0, testCount = 0;
+    // rayCount, testCount: the closest-hit queries and ray-shape evaluations of the reference for these pixels;
+    // tracedCount: the queries made here (shadow rays whose answer cannot matter are not shot, see the lights' loop)
+    unsigned long long rayCount = 0, testCount = 0, tracedCount = 0;
 #ifdef GRAFT_STAMPS  // diagnostic build only: shader-clock cycles per wave in the closest-hit call and in total
     unsigned long long stampHit = 0, stampRounds = 0, stampLoop = 0;
     const unsigned long long stampBegin = clock64();
@@ -247,8 +249,12 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
 #endif
                 Hit h;
                 const unsigned avoided = closest(o, d, mode, li, depth, mode == M_SHADOW ? tLimit : INFINITY, h);
-                rayCount++;
-                testCount += (unsigned)P.numShapes - avoided;
+                tracedCount++;
+                if (mode != M_SHADOW) {  // (a hit's shadow rays are booked when it is found)
+                    rayCount++;
+                    testCount += (unsigned)P.numShapes;
+                }
+                (void)avoided;
 #ifdef GRAFT_STAMPS
                 const unsigned long long stamp1 = clock64();
                 if (lane == (int)__builtin_ctzll(__ballot(1))) {  // one lane of those in this trip books the time
@@ -286,8 +292,14 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         }
                         litW = 0;
                         litLight = -1;
-                        li = 0;
-                        if (P.numLights > 0) startShadow(0);
+                        // lighting() (mainTracing.c:196-229) shoots a shadow ray per light, first to last, and every
+                        // unshadowed light OVERWRITES rgb (:223-225): its result is the last unshadowed light's.  So
+                        // the lights are gone through last to first and the first one found unshadowed ends the loop:
+                        // what the lights before it would have answered is never looked at by the reference either.
+                        rayCount += (unsigned)P.numLights;
+                        testCount += (unsigned long long)P.numLights * (unsigned)P.numShapes - (unsigned)P.avoidTotal;
+                        li = P.numLights - 1;
+                        if (P.numLights > 0) startShadow(li);
                         else finalize = true;
                     }
                 } else {  // M_SHADOW: mainTracing.c:210-226
@@ -317,7 +329,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         litW = w < 0 ? 0 : w;
                         litLight = li;
                     }
-                    if (++li < P.numLights) startShadow(li);
+                    if (!lit && --li >= 0) startShadow(li);
                     else finalize = true;
                 }
 
@@ -477,6 +489,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         for (int off = 32; off > 0; off >>= 1) {
             rayCount += __shfl_down(rayCount, off);
             testCount += __shfl_down(testCount, off);
+            tracedCount += __shfl_down(tracedCount, off);
 #ifdef GRAFT_STAMPS
             stampHit += __shfl_down(stampHit, off);
             stampRounds += __shfl_down(stampRounds, off);
@@ -486,12 +499,13 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         if (lane == 0) {
             atomicAdd(P.counters, rayCount);
             atomicAdd(P.counters + 1, testCount);
+            atomicAdd(P.counters + 2, tracedCount);
 #ifdef GRAFT_STAMPS
-            atomicAdd(P.counters + 2, (unsigned long long)(clock64() - stampBegin));
-            atomicAdd(P.counters + 3, stampHit);
-            atomicAdd(P.counters + 4, stampRounds);
-            atomicAdd(P.counters + 5, 1ull);
-            atomicAdd(P.counters + 6, stampLoop);
+            atomicAdd(P.counters + 4, (unsigned long long)(clock64() - stampBegin));
+            atomicAdd(P.counters + 5, stampHit);
+            atomicAdd(P.counters + 6, stampRounds);
+            atomicAdd(P.counters + 7, 1ull);
+            atomicAdd(P.counters + 8, stampLoop);
 #endif
         }
     }
@@ -1165,7 +1179,7 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
     GraftJob *jobs[kMaxDevices] = {nullptr};
     std::vector<int> first, count, owner;
     std::vector<size_t> at;  // a piece's first row inside its owner's buffer
-    GraftCounters sum = {0, 0};
+    GraftCounters sum = {0, 0, 0, 0};
     Device &root = gDevices[0];
     int nPieces = 0, rounds = 0, nCols = 0, nRows = 0;
     size_t ownedRows[kMaxDevices] = {0};
@@ -1238,10 +1252,11 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
         HIP_GO(hipStreamSynchronize(gDevices[d].stream));
         HIP_GO(hipStreamSynchronize(gDevices[d].moveStream));
         if (countersHost) {
-            GraftCounters c = {0, 0};
+            GraftCounters c = {0, 0, 0, 0};
             HIP_GO(hipMemcpy(&c, gDevices[d].counters.ptr, sizeof c, hipMemcpyDeviceToHost));
             sum.rays += c.rays;
             sum.tests += c.tests;
+            sum.raysTraced += c.raysTraced;
         }
     }
     HIP_GO(hipSetDevice(0));

@@ -215,6 +215,8 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     P.numShapes = nS; P.numLights = nL; P.numRuns = (int)runs.size(); P.numSpheres = (int)(sph.size() / 4);
     P.nCols = view->nCols; P.nRows = view->nRows;
     P.geomDoubles = (int)(sph.size() + pln.size());
+    P.avoidTotal = 0;
+    for (int i = 0; i < nL; ++i) P.avoidTotal += lights[i].avoidNum;
     P.fusedMiss = 1;
     for (size_t k = 0; k < sph.size() / 4; ++k)
         if (sph[4 * k + 3] < 1e-280) P.fusedMiss = 0;

@@ -81,6 +81,7 @@ struct TraceParams {
     int tilesPerTicket;        // consecutive tiles a wave takes per draw from a counter
     int prefetchTickets;       // draw the next ticket one ticket ahead (plenty of tickets per wave)
     int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
+    int avoidTotal;            // shapes on the lights' avoid lists, all lights together (ray-shape evaluations they spare)
     int fusedMiss;             // no sphere has a squared radius below 1e-280: the exact loop may prove misses with FMAs
     int format;
     int filterFloats;          // floats of the single-precision screen table staged in LDS, 0 = no screen
@@ -112,7 +113,7 @@ struct TraceParams {
     const double *colOff, *rowOff;
     void *frame;
     int *hitIndex;
-    unsigned long long *counters;  // {rays, tests} or null
+    unsigned long long *counters;  // GraftCounters or null
     int *tileCursor;
 };
 

@@ -239,7 +239,8 @@ class RayTracer:
         self.maxDepthHigh = 10
         self.ambientLight = 0.1                                    # :67
         self.frame = np.zeros((self.HEIGHT, self.WIDTH, 3))        # what the display would show (pixSetRGB sink)
-        self.last_counters = None
+        self.last_counters = None      # (closest-hit queries, ray-shape evaluations) of the reference for the last trace
+        self.last_rays_traced = None   # closest-hit queries the library made for it
 
     # -- scene construction (mainTracing.c:447-548) --
     def _place(self, index, s):
@@ -454,6 +455,7 @@ class RayTracer:
         del keep
         if want_counters:
             self.last_counters = (counters.rays, counters.tests)
+            self.last_rays_traced = counters.raysTraced
         return (frame, index) if want_index else frame
 
     def render_frame_multi(self, fmt=GRAFT_OUT_F64_RGB, pieces_per_device=8, want_index=False, want_counters=False):
@@ -471,6 +473,7 @@ class RayTracer:
         del keep
         if want_counters:
             self.last_counters = (counters.rays, counters.tests)
+            self.last_rays_traced = counters.raysTraced
         return (frame, index) if want_index else frame
 
     def render_rows_no_alloc(self, row0, n_rows, fmt, frame_ptr, index_ptr=None, counters_ptr=None, stream=None):

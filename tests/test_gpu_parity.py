@@ -36,6 +36,8 @@ def assert_parity(rt, row0=0, n_rows=None):
     extra = rgb.shape[0] * rgb.shape[1] if (rt.aliasing or rt.maxDepth <= 0) else 0
     assert rays == want["counters"][0] + extra
     assert tests == want["counters"][1] + extra * rt.numShapes
+    # the queries really made: all but the shadow rays whose answer a later light of the same hit overwrites
+    assert rt.last_rays_traced == want["counters"][0] + extra - want["counters"][3]
     return rgb, idx
 
 

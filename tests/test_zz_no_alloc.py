@@ -18,7 +18,7 @@ def both(rt, row0, n_rows, fmt=GRAFT_OUT_F64_RGB):
     dtype, ch = (torch.float64, 3) if fmt == GRAFT_OUT_F64_RGB else (torch.float32, 4)
     frame = torch.full((n_rows, want_rgb.shape[1], ch), -1.0, dtype=dtype, device=dev)
     index = torch.full((n_rows, want_rgb.shape[1]), -9, dtype=torch.int32, device=dev)
-    counters = torch.zeros(2, dtype=torch.int64, device=dev)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)  # one GraftCounters
     torch.cuda.synchronize()
     rt.render_rows_no_alloc(row0, n_rows, fmt, frame.data_ptr(), index.data_ptr(), counters.data_ptr())
     check(lib.graftSynchronize())
@@ -26,7 +26,8 @@ def both(rt, row0, n_rows, fmt=GRAFT_OUT_F64_RGB):
     assert np.array_equal(got.view(np.uint64 if fmt == GRAFT_OUT_F64_RGB else np.uint32),
                           want_rgb.view(np.uint64 if fmt == GRAFT_OUT_F64_RGB else np.uint32))
     assert np.array_equal(index.cpu().numpy(), want_idx)
-    assert tuple(int(c) for c in counters.cpu()) == tuple(want_counters)
+    assert tuple(int(c) for c in counters.cpu()[:2]) == tuple(want_counters)
+    assert int(counters[2]) == rt.last_rays_traced
 
 
 def test_no_alloc_entry_matches_render_rows(gpu):
