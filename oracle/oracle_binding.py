@@ -28,7 +28,7 @@ class OracleJob(ctypes.Structure):
                 ("aliasing", ctypes.c_int32), ("numPasses", ctypes.c_int32),
                 ("subStepX", ctypes.c_double), ("subStepY", ctypes.c_double),
                 ("nCols", ctypes.c_int32), ("nRows", ctypes.c_int32),
-                ("colOff", _dp), ("rowOff", _dp)]
+                ("colOff", _dp), ("rowOff", _dp), ("boundedShading", ctypes.c_int32)]
 
 
 _lib = None
@@ -79,6 +79,11 @@ def cam_initialize(target, view_dir, to_screen, to_cam):
 class Prepared:
     """OracleJob + the numpy arrays it points into."""
 
+    @staticmethod
+    def shape_colour(s):
+        """R, G, B of a shape: unif[4:7] of a sphere (shapes.c:144-147), unif[6:9] of a plane (:114-116)."""
+        return list(s.unif[4:7]) if s.kind == 0 else list(s.unif[6:9])
+
     def __init__(self, st):
         n, m = int(st.numShapes), int(st.numLights)
         self.kind = np.zeros(max(n, 1), dtype=np.int32)
@@ -127,6 +132,10 @@ class Prepared:
         J.nCols, J.nRows = len(self.cols), len(self.rows)
         J.colOff = self.cols.ctypes.data_as(_dp)
         J.rowOff = self.rows.ctypes.data_as(_dp)
+        colours = np.concatenate([self.lcol[:m].ravel(), np.array([c for k in range(n) for c in self.shape_colour(st.shapes[k])])])
+        weights = self.material[:n][:, [0, 1, 3]].ravel()
+        J.boundedShading = int(bool(np.all(np.isfinite(colours)) and np.all(np.isfinite(weights))
+                                    and (colours.size == 0 or np.abs(colours).max() < 1e150)))
         self.WIDTH, self.HEIGHT = int(st.WIDTH), int(st.HEIGHT)
         self.screenWidth, self.screenHeight = float(st.screenWidth), float(st.screenHeight)
 

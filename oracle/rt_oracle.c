@@ -57,10 +57,14 @@ typedef struct OracleJob {
     int32_t nCols, nRows;   /* trip counts of the loops at mainTracing.c:392-393 */
     const double *colOff;   /* the values i takes, in order */
     const double *rowOff;   /* the values j takes, in order */
+    int32_t boundedShading; /* every colour, weight and colour product of the job is finite (only used for the count
+                             * of queries the product does not make; no result depends on it) */
 } OracleJob;
 
-/* overwritten: shadow rays of lights that come before the last unshadowed light of their hit -- queries whose
- * answers mainTracing.c:223-225 overwrites (the product does not make them and reports how many it made) */
+/* overwritten: shadow rays whose answer cannot reach the pixel -- those of lights that come before the last
+ * unshadowed light of their hit (mainTracing.c:223-225 overwrites what they gave) and, where every colour and weight
+ * of the job is finite, those of the lights before the first one that may lie in front of the surface (a light
+ * behind it gives diffInt = 0, :219).  The product does not make these queries and reports how many it made. */
 typedef struct Counters { uint64_t rays, tests, shoots, overwritten; } Counters;
 
 /* ---- vector.c ---- */
@@ -210,7 +214,21 @@ static void diffuse(const OracleJob *J, const double loc[3], const double normal
             v3copy(c, rgb);
         }
     }
-    if (lastLit > 0) C->overwritten += (uint64_t)lastLit;
+    /* the product's rule, restated: lights [0, firstFront) are certainly behind the surface */
+    int firstFront = 0;
+    if (J->boundedShading) {
+        const double nn = normal[0] * normal[0] + normal[1] * normal[1] + normal[2] * normal[2];
+        firstFront = J->numLights;
+        for (int i = 0; i < J->numLights; ++i) {
+            const double *lloc = J->lightLoc + 3 * i;
+            const double bx = lloc[0] - loc[0], by = lloc[1] - loc[1], bz = lloc[2] - loc[2];
+            const double q = bx * normal[0] + by * normal[1] + bz * normal[2];
+            const double bb = bx * bx + by * by + bz * bz;
+            if (!(q < 0 && q * q > 1e-20 * (bb * nn))) { firstFront = i; break; }
+        }
+    }
+    const int lowestAsked = lastLit > firstFront ? lastLit : firstFront;  /* lights [lowestAsked, numLights) are asked */
+    C->overwritten += (uint64_t)(lowestAsked < J->numLights ? lowestAsked : J->numLights);
 }
 
 /* mainTracing.c:232-270, bug for bug: the POSITION s (not the direction d) is scaled by eta and used both in

@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             const size_t pixel = (size_t)by * P.nCols + ix;
             // per-lane machine state
             int mode, depth = 0, sample = 0, li = 0, sp = 0, hitIdx = -1, litLight = -1;
+            int firstFront = 0;                // lights below this index cannot change the hit's colour
             double o[3], d[3];                 // current ray
             double loc[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, din[3] = {0, 0, 0};  // shaded hit: point, normal, incoming dir
             double litW = 0;
@@ -298,8 +299,29 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         // what the lights before it would have answered is never looked at by the reference either.
                         rayCount += (unsigned)P.numLights;
                         testCount += (unsigned long long)P.numLights * (unsigned)P.numShapes - (unsigned)P.avoidTotal;
+                        // A light behind the surface (cosine with the normal below zero) adds nothing whether it is
+                        // shadowed or not (diffInt < 0 ? 0, :219); its shadow ray only decides whether the lights
+                        // BEFORE it are overwritten.  Below the first light that may lie in front of the surface no
+                        // ray can change the result: lights [0, firstFront) are not asked.  (Jobs whose colours and
+                        // weights are not all finite ask every light: there 0 * colour is not 0.)
+                        firstFront = 0;
+                        if (P.boundedShading) {
+                            const double nn = nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2];
+                            firstFront = P.numLights;
+                            for (int i = 0; i < P.numLights; ++i) {
+                                const DevLight &Li = P.lights[i];
+                                const double bx = Li.loc[0] - loc[0], by2 = Li.loc[1] - loc[1], bz = Li.loc[2] - loc[2];
+                                const double q = bx * nrm[0] + by2 * nrm[1] + bz * nrm[2];
+                                const double bb = bx * bx + by2 * by2 + bz * bz;
+                                // behind for certain: the cosine the reference computes is below -1e-10, far from its rounding
+                                if (!(q < 0 && q * q > 1e-20 * (bb * nn))) {
+                                    firstFront = i;
+                                    break;
+                                }
+                            }
+                        }
                         li = P.numLights - 1;
-                        if (P.numLights > 0) startShadow(li);
+                        if (li >= firstFront) startShadow(li);
                         else finalize = true;
                     }
                 } else {  // M_SHADOW: mainTracing.c:210-226
@@ -329,7 +351,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         litW = w < 0 ? 0 : w;
                         litLight = li;
                     }
-                    if (!lit && --li >= 0) startShadow(li);
+                    if (!lit && --li >= firstFront) startShadow(li);
                     else finalize = true;
                 }
 

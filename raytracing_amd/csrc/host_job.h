@@ -217,6 +217,24 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     P.geomDoubles = (int)(sph.size() + pln.size());
     P.avoidTotal = 0;
     for (int i = 0; i < nL; ++i) P.avoidTotal += lights[i].avoidNum;
+    {   // largest magnitudes of light and shape colours: their products must stay finite
+        double maxLight = 0, maxShape = 0;
+        bool finite = true;
+        for (int i = 0; i < nL; ++i)
+            for (int c = 0; c < 3; ++c) {
+                finite = finite && std::isfinite(lights[i].color[c]);
+                maxLight = fmax(maxLight, fabs(lights[i].color[c]));
+            }
+        for (int k = 0; k < nS; ++k) {
+            const DevMaterial &m = mats[k];
+            for (int c = 0; c < 3; ++c) {
+                finite = finite && std::isfinite(m.color[c]);
+                maxShape = fmax(maxShape, fabs(m.color[c]));
+            }
+            finite = finite && std::isfinite(m.reflectivity) && std::isfinite(m.ambientLight) && std::isfinite(m.transparency);
+        }
+        P.boundedShading = finite && maxLight < 1e150 && maxShape < 1e150 ? 1 : 0;
+    }
     P.fusedMiss = 1;
     for (size_t k = 0; k < sph.size() / 4; ++k)
         if (sph[4 * k + 3] < 1e-280) P.fusedMiss = 0;

@@ -82,6 +82,7 @@ struct TraceParams {
     int prefetchTickets;       // draw the next ticket one ticket ahead (plenty of tickets per wave)
     int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
     int avoidTotal;            // shapes on the lights' avoid lists, all lights together (ray-shape evaluations they spare)
+    int boundedShading;        // every colour, weight and colour product of the job is finite (0 * colour = 0)
     int fusedMiss;             // no sphere has a squared radius below 1e-280: the exact loop may prove misses with FMAs
     int format;
     int filterFloats;          // floats of the single-precision screen table staged in LDS, 0 = no screen
