@@ -28,7 +28,7 @@ class OracleJob(ctypes.Structure):
                 ("aliasing", ctypes.c_int32), ("numPasses", ctypes.c_int32),
                 ("subStepX", ctypes.c_double), ("subStepY", ctypes.c_double),
                 ("nCols", ctypes.c_int32), ("nRows", ctypes.c_int32),
-                ("colOff", _dp), ("rowOff", _dp), ("boundedShading", ctypes.c_int32)]
+                ("colOff", _dp), ("rowOff", _dp), ("skipLightsBehind", ctypes.c_int32)]
 
 
 _lib = None
@@ -134,8 +134,8 @@ class Prepared:
         J.rowOff = self.rows.ctypes.data_as(_dp)
         colours = np.concatenate([self.lcol[:m].ravel(), np.array([c for k in range(n) for c in self.shape_colour(st.shapes[k])])])
         weights = self.material[:n][:, [0, 1, 3]].ravel()
-        J.boundedShading = int(bool(np.all(np.isfinite(colours)) and np.all(np.isfinite(weights))
-                                    and (colours.size == 0 or np.abs(colours).max() < 1e150)))
+        J.skipLightsBehind = int(bool(n >= 32 and m <= 31 and np.all(np.isfinite(colours)) and np.all(np.isfinite(weights))
+                                      and (colours.size == 0 or np.abs(colours).max() < 1e150)))
         self.WIDTH, self.HEIGHT = int(st.WIDTH), int(st.HEIGHT)
         self.screenWidth, self.screenHeight = float(st.screenWidth), float(st.screenHeight)
 

@@ -57,13 +57,13 @@ typedef struct OracleJob {
     int32_t nCols, nRows;   /* trip counts of the loops at mainTracing.c:392-393 */
     const double *colOff;   /* the values i takes, in order */
     const double *rowOff;   /* the values j takes, in order */
-    int32_t boundedShading; /* every colour, weight and colour product of the job is finite (only used for the count
-                             * of queries the product does not make; no result depends on it) */
+    int32_t skipLightsBehind; /* the product's rule for this job (finite colours and weights, 32 shapes or more); only
+                               * used for the count of queries the product does not make: no result depends on it */
 } OracleJob;
 
 /* overwritten: shadow rays whose answer cannot reach the pixel -- those of lights that come before the last
  * unshadowed light of their hit (mainTracing.c:223-225 overwrites what they gave) and, where every colour and weight
- * of the job is finite, those of the lights before the first one that may lie in front of the surface (a light
+ * of the job is finite and the scene has 32 shapes or more, those of the lights before the first one that may lie in front of the surface (a light
  * behind it gives diffInt = 0, :219).  The product does not make these queries and reports how many it made. */
 typedef struct Counters { uint64_t rays, tests, shoots, overwritten; } Counters;
 
@@ -216,7 +216,7 @@ static void diffuse(const OracleJob *J, const double loc[3], const double normal
     }
     /* the product's rule, restated: lights [0, firstFront) are certainly behind the surface */
     int firstFront = 0;
-    if (J->boundedShading) {
+    if (J->skipLightsBehind) {
         const double nn = normal[0] * normal[0] + normal[1] * normal[1] + normal[2] * normal[2];
         firstFront = J->numLights;
         for (int i = 0; i < J->numLights; ++i) {

@@ -188,7 +188,6 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             const size_t pixel = (size_t)by * P.nCols + ix;
             // per-lane machine state
             int mode, depth = 0, sample = 0, li = 0, sp = 0, hitIdx = -1, litLight = -1;
-            int firstFront = 0;                // lights below this index cannot change the hit's colour
             double o[3], d[3];                 // current ray
             double loc[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, din[3] = {0, 0, 0};  // shaded hit: point, normal, incoming dir
             double litW = 0;
@@ -213,6 +212,27 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 rayReflects = 1;  // launchRays passes shouldReflect = 1, mainTracing.c:391
                 mode = M_RADIANCE;
             };
+            // Which lights may lie in front of the surface at the hit being shaded (bit i = light i)?  "Behind" only
+            // when the cosine the reference computes is below -1e-10 for certain, far from its rounding.  The loop is
+            // the same for all lanes, so the lights' positions come through scalar loads.  (Jobs whose colours and
+            // weights are not all finite -- there 0 * colour is not 0 --, small scenes and jobs with more than 31
+            // lights take every light to be in front.)
+            unsigned frontMask = ~0u;
+            auto findFront = [&]() {
+                frontMask = ~0u;
+                if (!P.skipLightsBehind || P.numLights > 31) return;
+                const ConstDoubles LD = (ConstDoubles)(unsigned long long)P.lights;
+                const double nn = nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2];
+                frontMask = 0;
+                for (int i = 0; i < P.numLights; ++i) {
+                    const double bx = LD[8 * i + 3] - loc[0], by2 = LD[8 * i + 4] - loc[1], bz = LD[8 * i + 5] - loc[2];
+                    const double q = bx * nrm[0] + by2 * nrm[1] + bz * nrm[2];
+                    const double bb = bx * bx + by2 * by2 + bz * bz;
+                    if (!(q < 0 && q * q > 1e-20 * (bb * nn))) frontMask |= 1u << i;
+                }
+            };
+            // may one of the lights 0 .. last shine on the hit?
+            auto mayShine = [&](int last) { return last >= 0 && (frontMask & (0xffffffffu >> (31 - min(last, 31)))) != 0; };
             auto startShadow = [&](int light) {  // mainTracing.c:200-205
                 const DevLight &L = P.lights[light];
                 d[0] = d[1] = d[2] = 0;
@@ -301,27 +321,11 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         testCount += (unsigned long long)P.numLights * (unsigned)P.numShapes - (unsigned)P.avoidTotal;
                         // A light behind the surface (cosine with the normal below zero) adds nothing whether it is
                         // shadowed or not (diffInt < 0 ? 0, :219); its shadow ray only decides whether the lights
-                        // BEFORE it are overwritten.  Below the first light that may lie in front of the surface no
-                        // ray can change the result: lights [0, firstFront) are not asked.  (Jobs whose colours and
-                        // weights are not all finite ask every light: there 0 * colour is not 0.)
-                        firstFront = 0;
-                        if (P.boundedShading) {
-                            const double nn = nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2];
-                            firstFront = P.numLights;
-                            for (int i = 0; i < P.numLights; ++i) {
-                                const DevLight &Li = P.lights[i];
-                                const double bx = Li.loc[0] - loc[0], by2 = Li.loc[1] - loc[1], bz = Li.loc[2] - loc[2];
-                                const double q = bx * nrm[0] + by2 * nrm[1] + bz * nrm[2];
-                                const double bb = bx * bx + by2 * by2 + bz * bz;
-                                // behind for certain: the cosine the reference computes is below -1e-10, far from its rounding
-                                if (!(q < 0 && q * q > 1e-20 * (bb * nn))) {
-                                    firstFront = i;
-                                    break;
-                                }
-                            }
-                        }
+                        // BEFORE it are overwritten.  Once every light still to be asked lies behind the surface
+                        // no ray can change the result: they are not asked (mayShine below).
                         li = P.numLights - 1;
-                        if (li >= firstFront) startShadow(li);
+                        findFront();
+                        if (mayShine(li)) startShadow(li);
                         else finalize = true;
                     }
                 } else {  // M_SHADOW: mainTracing.c:210-226
@@ -351,7 +355,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         litW = w < 0 ? 0 : w;
                         litLight = li;
                     }
-                    if (!lit && --li >= firstFront) startShadow(li);
+                    if (!lit && mayShine(--li)) startShadow(li);
                     else finalize = true;
                 }
 

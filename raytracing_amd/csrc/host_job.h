@@ -233,7 +233,10 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
             }
             finite = finite && std::isfinite(m.reflectivity) && std::isfinite(m.ambientLight) && std::isfinite(m.transparency);
         }
-        P.boundedShading = finite && maxLight < 1e150 && maxShape < 1e150 ? 1 : 0;
+        // Small scenes keep asking every light down to the first unshadowed one: there the closest-hit query is
+        // cheap next to the shading code, and lanes that drop a query fall out of step with their wave, which then
+        // runs the code of every stage in every round (start-up scene, 11 shapes: 3.98 instead of 2.70 ms).
+        P.skipLightsBehind = finite && maxLight < 1e150 && maxShape < 1e150 && nS >= kSkipBehindMinShapes ? 1 : 0;
     }
     P.fusedMiss = 1;
     for (size_t k = 0; k < sph.size() / 4; ++k)

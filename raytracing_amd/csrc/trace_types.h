@@ -19,6 +19,7 @@ constexpr int kSmallBlock = 256;    // scenes whose geometry fits a quarter of t
 #endif
 constexpr int kLargeBlock = GRAFT_LARGE_BLOCK;   // one workgroup per CU sharing up to the whole LDS
 constexpr int kGeomPad = 32;        // doubles of never-hit padding behind the packed geometry (the exact loop reads ahead)
+constexpr int kSkipBehindMinShapes = 32;
 constexpr int kCursors = 16;        // ticket counters of the many-counter kernels ...
 constexpr int kCursorStride = 32;   // ... one per 128-byte line
 constexpr size_t kLdsSmall = 36 * 1024;
@@ -82,7 +83,8 @@ struct TraceParams {
     int prefetchTickets;       // draw the next ticket one ticket ahead (plenty of tickets per wave)
     int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
     int avoidTotal;            // shapes on the lights' avoid lists, all lights together (ray-shape evaluations they spare)
-    int boundedShading;        // every colour, weight and colour product of the job is finite (0 * colour = 0)
+    int skipLightsBehind;      // lights behind the shaded surface may go unasked: every colour, weight and colour product of
+                               // the job is finite (0 * colour = 0) and the scene has kSkipBehindMinShapes shapes or more
     int fusedMiss;             // no sphere has a squared radius below 1e-280: the exact loop may prove misses with FMAs
     int format;
     int filterFloats;          // floats of the single-precision screen table staged in LDS, 0 = no screen
