@@ -87,6 +87,26 @@ def test_gpu_matches_oracle_counters(gpu, name):
     assert_parity(build(name))
 
 
+def test_queries_not_made(gpu):
+    """The shadow rays the library does not shoot (lights before the last unshadowed one; lights behind the surface
+    once no light in front remains to be asked): frames and the reference's counts as ever, and the number of queries
+    made is the one the oracle predicts -- with several lights, with a colour too large for "0 * colour = 0" to be
+    relied on (every light down to the first unshadowed one is asked then), and in a small scene (likewise)."""
+    import test_gpu_screens as ts
+    rt = ts.scene(61, 120, lights=5, refl=0.4, depth=3)
+    assert_parity(rt)
+    made, reference = rt.last_rays_traced, rt.last_counters[0]
+    assert made < 0.8 * reference
+    rt.lights[1].color = [1e200, 0.5, 0.5]
+    assert_parity(rt)
+    assert made < rt.last_rays_traced < reference       # the second rule is off for this job
+    small = ts.scene(62, 20, lights=4)
+    assert_parity(small)
+    lone = ts.scene(63, 80, lights=1)
+    assert_parity(lone)
+    assert lone.last_rays_traced < lone.last_counters[0]  # one light: only the second rule spares anything
+
+
 def test_output_formats(gpu):
     rt = build("mixed_2")
     f64 = rt.render_rows(0, None, GRAFT_OUT_F64_RGB)
