@@ -233,16 +233,11 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             };
             // may one of the lights 0 .. last shine on the hit?
             auto mayShine = [&](int last) { return last >= 0 && (frontMask & (0xffffffffu >> (31 - min(last, 31)))) != 0; };
-            auto startShadow = [&](int light) {  // mainTracing.c:200-205
-                const DevLight &L = P.lights[light];
-                d[0] = d[1] = d[2] = 0;
-                unit3(L.loc[0] - loc[0], L.loc[1] - loc[1], L.loc[2] - loc[2], d[0], d[1], d[2]);
-                o[0] = loc[0] + .000001 * d[0];
-                o[1] = loc[1] + .000001 * d[1];
-                o[2] = loc[2] + .000001 * d[2];
-                mode = M_SHADOW;
-                if (SCREEN == 5) tLimit = (L.loc[0] - o[0]) * d[0] + (L.loc[1] - o[1]) * d[1] + (L.loc[2] - o[2]) * d[2];
-            };
+            // The stages of a round do not start the lane's next ray themselves: they say which kind it is, and ONE
+            // piece of code at the end of the round normalises its direction and sets its origin for all lanes
+            // together.  (Lanes of a wave are in different stages: each stage doing this for itself would run the
+            // square root and the three divisions of vecUnit up to three times per round.)
+            enum { NEXT_NONE = 0, NEXT_SHADOW = 1, NEXT_MIRROR = 2, NEXT_SAMPLE = 3 };
 
             // maxDepth <= 0: shootRay returns black before it looks at the scene (mainTracing.c:302-306), for every
             // sample; with anti-aliasing the background-seeded sum (:395) takes n additions of zero
@@ -285,14 +280,13 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
 #endif
 
                 bool finalize = false, unwind = false;
+                int next = NEXT_NONE;
                 double v[3] = {0, 0, 0};
                 if (mode == M_INDEX) {
                     firstIdx = h.idx;
                     if (traceNothing) mode = M_DONE;
-                    else startSample(0);
-                    continue;
-                }
-                if (mode == M_RADIANCE) {
+                    else next = NEXT_SAMPLE;
+                } else if (mode == M_RADIANCE) {
                     if (depth == 0 && sample == 0 && !P.aliasing) firstIdx = h.idx;
                     if (h.idx < 0) {  // mainTracing.c:314-317
                         v[0] = cam[CAM_BACKGROUND]; v[1] = cam[CAM_BACKGROUND + 1]; v[2] = cam[CAM_BACKGROUND + 2];
@@ -325,7 +319,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         // no ray can change the result: they are not asked (mayShine below).
                         li = P.numLights - 1;
                         findFront();
-                        if (mayShine(li)) startShadow(li);
+                        if (mayShine(li)) next = NEXT_SHADOW;
                         else finalize = true;
                     }
                 } else {  // M_SHADOW: mainTracing.c:210-226
@@ -355,7 +349,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         litW = w < 0 ? 0 : w;
                         litLight = li;
                     }
-                    if (!lit && mayShine(--li)) startShadow(li);
+                    if (!lit && mayShine(--li)) next = NEXT_SHADOW;
                     else finalize = true;
                 }
 
@@ -418,12 +412,10 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                                 unwind = true;              // v stays 0
                             } else {  // reflection(), mainTracing.c:180-190
                                 const double k2 = 2 * dot3(din[0], din[1], din[2], nrm[0], nrm[1], nrm[2]);
-                                double rx = din[0] - k2 * nrm[0], ry = din[1] - k2 * nrm[1], rz = din[2] - k2 * nrm[2];
-                                unit3(rx, ry, rz, rx, ry, rz);
-                                d[0] = rx; d[1] = ry; d[2] = rz;
-                                o[0] = loc[0] + .000001 * rx;
-                                o[1] = loc[1] + .000001 * ry;
-                                o[2] = loc[2] + .000001 * rz;
+                                d[0] = din[0] - k2 * nrm[0];  // (normalised in place below, as the reference does)
+                                d[1] = din[1] - k2 * nrm[1];
+                                d[2] = din[2] - k2 * nrm[2];
+                                next = NEXT_MIRROR;
                                 depth++;
                                 rayReflects = 1;  // reflection() passes shouldReflect = 1, :181
                                 mode = M_RADIANCE;
@@ -494,8 +486,48 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                             acc[0] = v[0]; acc[1] = v[1]; acc[2] = v[2];
                         }
                         sample++;
-                        if (sample < nSamples) startSample(sample);
+                        if (sample < nSamples) next = NEXT_SAMPLE;
                         else mode = M_DONE;
+                    }
+                }
+
+                if (next != NEXT_NONE) {  // the lane's next ray
+                    double vx, vy, vz;
+                    if (next == NEXT_SHADOW) {  // mainTracing.c:200-205
+                        const DevLight &L = P.lights[li];
+                        vx = L.loc[0] - loc[0]; vy = L.loc[1] - loc[1]; vz = L.loc[2] - loc[2];
+                        d[0] = d[1] = d[2] = 0;
+                        mode = M_SHADOW;
+                    } else if (next == NEXT_MIRROR) {  // reflection(), mainTracing.c:180-190
+                        vx = d[0]; vy = d[1]; vz = d[2];
+                    } else {  // the sample's primary ray, mainTracing.c:401-417 / :425-437
+                        double xo = colI, yo = rowJ;
+                        if (P.aliasing) {  // k outer, l inner
+                            const int k = sample / P.numPasses, l = sample - k * P.numPasses;
+                            xo = colI + cam[CAM_SUBX] * (double)(k + 1);
+                            yo = rowJ + cam[CAM_SUBY] * (double)(l + 1);
+                        }
+                        screenPoint(cam, xo, yo, o);
+                        if (P.projectionType == GRAFT_ORTHOGRAPHIC) {
+                            vx = -cam[CAM_VIEW]; vy = -cam[CAM_VIEW + 1]; vz = -cam[CAM_VIEW + 2];
+                        } else {
+                            vx = o[0] - cam[CAM_POS]; vy = o[1] - cam[CAM_POS + 1]; vz = o[2] - cam[CAM_POS + 2];
+                        }
+                        d[0] = d[1] = d[2] = 0;
+                        depth = 0;
+                        sp = 0;
+                        rayReflects = 1;  // launchRays passes shouldReflect = 1, mainTracing.c:391
+                        mode = M_RADIANCE;
+                    }
+                    unit3(vx, vy, vz, d[0], d[1], d[2]);
+                    if (next != NEXT_SAMPLE) {  // vecNudge, mainTracing.c:163-167
+                        o[0] = loc[0] + .000001 * d[0];
+                        o[1] = loc[1] + .000001 * d[1];
+                        o[2] = loc[2] + .000001 * d[2];
+                    }
+                    if (SCREEN == 5 && next == NEXT_SHADOW) {
+                        const DevLight &L = P.lights[li];
+                        tLimit = (L.loc[0] - o[0]) * d[0] + (L.loc[1] - o[1]) * d[1] + (L.loc[2] - o[2]) * d[2];
                     }
                 }
             }
