@@ -403,6 +403,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "config": {"workload": desc, "frame": [W, H], "output": "float4 RGBA in HBM",
                                             "screen_level": job.screen_level(),
+                                            "rays_counted": "closest-hit queries the kernel made (%.4g per frame); the "
+                                                            "reference makes %.4g for the same frame, see `reference`"
+                                                            % (rays, ref_rays),
                                             "parallelism": ("1 GPU" if world == 1 else "rows dealt round-robin in %d pieces per GPU x%d, "
                                                             "RCCL send/recv to rank 0 pipelined behind tracing"
                                                             % (args.chunks, world))},
