@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 baseline on the GPU box: quick parity check, bench lines, level-0 (exact double loop) profile of cfg3,
+# Baseline on the GPU box: quick parity check, bench lines, level-0 (exact double loop) profile of cfg3,
 # LDS counters of cfg4.  Every GPU step has its own time limit; the script stops at the first failure.
 set -e
 OUT=gpurun_out/r2_base

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 final measurements on the GPU box: counter records + kernel stats per workload, bench lines.
+# Final measurements on the GPU box: bench lines per workload (counter records are collected beforehand, see below).
 set -e
 # (counter records first: bash profiles/collect_all.sh <tag>, then profiles/summarize_pmc.py per workload, so that the bench lines find records of this build)
 mkdir -p gpurun_out/r2_final
