@@ -37,3 +37,7 @@ if c[12]:
     print("   grid walk: %d calls (%.1f lanes each), %.1f loop iterations per call with %.1f lanes alive on average, "
           "%.0f cycles per call (%.1f%% of wave time), %.1f cycles per iteration"
           % (c[12], c[13] / c[12], c[10] / c[12], c[11] / max(c[10], 1), c[14] / c[12], 100.0 * c[14] / total, c[14] / max(c[10], 1)))
+st = c[15:19]  # (stamp counters 17..20 of the kernel, two GraftCounters words taken out above)
+if sum(st):
+    print("   stages behind the query, shares of wave time: query result %.1f%%, shading %.1f%%, hand-up/sample end %.1f%%, "
+          "next ray %.1f%%" % tuple(100.0 * x / total for x in st))

@@ -279,6 +279,17 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 }
 #endif
 
+#ifdef GRAFT_STAMPS  // shader-clock shares of the stages behind the query: booked by the first lane present at each mark
+                unsigned long long stampMark = clock64();
+                auto stampStage = [&](int which) {
+                    const unsigned long long now = clock64();
+                    if (P.counters && lane == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 17 + which, now - stampMark);
+                    stampMark = now;
+                };
+#define GRAFT_STAGE(which) stampStage(which)
+#else
+#define GRAFT_STAGE(which)
+#endif
                 bool finalize = false, unwind = false;
                 int next = NEXT_NONE;
                 double v[3] = {0, 0, 0};
@@ -353,6 +364,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     else finalize = true;
                 }
 
+                GRAFT_STAGE(0);  // what the query found: hit (normal, lights in front) or shadow result
                 if (finalize) {  // mainTracing.c:330-369 for the level whose hit is (hitIdx, loc, nrm, din)
                     const DevMaterial &m = P.materials[hitIdx];
                     const double rgb[3] = {m.color[0], m.color[1], m.color[2]};
@@ -444,6 +456,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     }
                 }
 
+                GRAFT_STAGE(1);  // shading of a finished hit
                 if (unwind) {  // a ray's value v is known: hand it up the tree, innermost first (:338, :363-369)
                     bool launched = false;
                     while (sp > 0 && !launched) {
@@ -491,6 +504,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     }
                 }
 
+                GRAFT_STAGE(2);  // values handed up, sample finished
                 if (next != NEXT_NONE) {  // the lane's next ray
                     double vx, vy, vz;
                     if (next == NEXT_SHADOW) {  // mainTracing.c:200-205
@@ -530,6 +544,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         tLimit = (L.loc[0] - o[0]) * d[0] + (L.loc[1] - o[1]) * d[1] + (L.loc[2] - o[2]) * d[2];
                     }
                 }
+                GRAFT_STAGE(3);  // next ray set up
             }
 #ifdef GRAFT_STAMPS
             if (loopLeader) stampLoop += clock64() - stampLoop0;
