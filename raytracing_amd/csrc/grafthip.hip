@@ -517,7 +517,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     } else {  // the sample's primary ray, mainTracing.c:401-417 / :425-437
                         double xo = colI, yo = rowJ;
                         if (P.aliasing) {  // k outer, l inner
-                            const int k = sample / P.numPasses, l = sample - k * P.numPasses;
+                            // k = sample / numPasses by a multiplication (exact below 2^20 samples, host_job.h)
+                            const int k = (int)__umulhi((unsigned)sample, P.numPassesRecip), l = sample - k * P.numPasses;
                             xo = colI + cam[CAM_SUBX] * (double)(k + 1);
                             yo = rowJ + cam[CAM_SUBY] * (double)(l + 1);
                         }

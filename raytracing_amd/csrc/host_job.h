@@ -238,6 +238,11 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
         // runs the code of every stage in every round (start-up scene, 11 shapes: 3.98 instead of 2.70 ms).
         P.skipLightsBehind = finite && maxLight < 1e150 && maxShape < 1e150 && nS >= kSkipBehindMinShapes ? 1 : 0;
     }
+    {   // numPasses <= 1024 (checked above), so samples < 2^20 and e = ceil(2^32 / n) n - 2^32 < n gives sample e < 2^30
+        const unsigned long long n = P.numPasses > 0 ? (unsigned long long)P.numPasses : 1;
+        const unsigned long long recip = ((1ull << 32) + n - 1) / n;
+        P.numPassesRecip = recip > 0xffffffffull ? 0xffffffffu : (unsigned)recip;  // (n = 1: the only sample is 0)
+    }
     P.fusedMiss = 1;
     for (size_t k = 0; k < sph.size() / 4; ++k)
         if (sph[4 * k + 3] < 1e-280) P.fusedMiss = 0;

@@ -85,6 +85,7 @@ struct TraceParams {
     int avoidTotal;            // shapes on the lights' avoid lists, all lights together (ray-shape evaluations they spare)
     int skipLightsBehind;      // lights behind the shaded surface may go unasked: every colour, weight and colour product of
                                // the job is finite (0 * colour = 0) and the scene has kSkipBehindMinShapes shapes or more
+    unsigned numPassesRecip;   // ceil(2^32 / numPasses): sample / numPasses = (sample * this) >> 32 for sample < 2^20
     int fusedMiss;             // no sphere has a squared radius below 1e-280: the exact loop may prove misses with FMAs
     int format;
     int filterFloats;          // floats of the single-precision screen table staged in LDS, 0 = no screen
