@@ -840,6 +840,150 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
     finishBest(closest, sx, sy, sz, dx, dy, dz, h);
 }
 
+// ---- candidate lists (SCREEN == 6) ------------------------------------------------------------------------------
+//
+// Sphere-only scenes seen in perspective.  Every ray of the path passes through a point that is known before the ray
+// is: a primary ray through the camera, a shadow ray through its light AND through a point of the sphere it starts
+// on.  That pins down, ahead of time, the few spheres such a ray can meet:
+//   * primary rays: the spheres whose cone, seen from the camera, overlaps the cone that bounds ALL primary rays of
+//     the wave's 8x8 tile (every sample of every pixel).  The wave works that list out once per tile, all lanes
+//     together, from the camera's two-level cone table (buildTileList), and keeps it in LDS;
+//   * shadow rays: the occluder list of (sphere, light), built on the host (packLightLists).
+// closestHitLists then runs the exact test (shapes.c:47-73) on the lane's own list, behind the single-precision screen
+// of closestHitScreened; lanes of a wave follow different lists, the instructions are shared.  A sphere that is on
+// no list of a ray has a provably negative discriminant in the reference (or can only be met beyond the light, which
+// lighting() treats like no hit, mainTracing.c:211-215), so hit masks, hit points and colours are unchanged.
+
+// The cone that bounds every primary ray of a tile, as (axis, cos, sin of the half-angle), and whether an entry
+// (a, -kappa2) of a cone table can be met by a line inside it.  The table's kappa2 = cos^2(A) - 16 u rounded down
+// (packConeTable; u = 2^-24) stands for an angle A' >= A with cos A' <= cos A - 4.8e-7; the entry is left out iff
+// |a . t| + 1e-9 < cos(A' + tau): then the angle between the axis t and the entry's axis (as lines) exceeds
+// A + tau even after the entry's axis was rounded to float (|a . t| is off by at most 1.2e-7), and every line within
+// tau of t misses the entry's cone.  Evaluated in double precision; once per tile and lane, so cost does not matter.
+struct TileCone {
+    double ax, ay, az, cosT, sinT;
+    bool ok;  // false: no usable bound (non-finite or wide): the tile lists every sphere
+};
+
+__device__ __forceinline__ bool coneMeetsTile(const float4v e, const TileCone &T) {
+    if (e.w >= 0.0f) return true;                     // kappa2 = -1: always passes
+    const double k2 = -(double)e.w;
+    if (!(k2 <= 1.0)) return false;                   // -inf: never passes (padding)
+    const double cosA = sqrt(k2), sinA = sqrt(1.0 - k2);
+    const double c = fabs((double)e.x * T.ax + (double)e.y * T.ay + (double)e.z * T.az);
+    return c + 1e-9 >= cosA * T.cosT - sinA * T.sinT;
+}
+
+// The wave's tile list: sphere numbers (16 bits) at `list` in LDS; returns the count, or -1 when the list would
+// exceed kTileListCap entries or the tile has no usable bounding cone (the caller then lists every sphere).  Called by
+// all 64 lanes.  (xLo, xHi) x (yLo, yHi): world offsets on the screen plane that bound every sample of the tile.
+__device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles C, double xLo, double xHi, double yLo,
+                                             double yHi, unsigned short *list) {
+    const int lane = lane64();
+    auto towards = [&](double x, double y, double v[3]) {
+        for (int a = 0; a < 3; ++a) v[a] = C[CAM_TOSCREEN + a] + x * C[CAM_LRUNIT + a] + y * C[CAM_UDUNIT + a];
+    };
+    TileCone T;
+    double t[3], v[3];
+    towards(0.5 * (xLo + xHi), 0.5 * (yLo + yHi), t);
+    const double tt = t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
+    const double inv = 1.0 / sqrt(tt);
+    T.ax = t[0] * inv; T.ay = t[1] * inv; T.az = t[2] * inv;
+    // lane c (mod 4) looks at corner c; a rectangle in a plane lies inside a cone when its corners do
+    towards((lane & 1) ? xHi : xLo, (lane & 2) ? yHi : yLo, v);
+    const double cx = T.ay * v[2] - T.az * v[1], cy = T.az * v[0] - T.ax * v[2], cz = T.ax * v[1] - T.ay * v[0];
+    const double vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    double s2 = (cx * cx + cy * cy + cz * cz) / vv;  // sin^2 of the angle between axis and corner
+    const double along = T.ax * v[0] + T.ay * v[1] + T.az * v[2];
+    if (!(along > 0) || !(s2 == s2)) s2 = 2.0;
+    s2 = fmax(s2, __shfl_xor(s2, 1));
+    s2 = fmax(s2, __shfl_xor(s2, 2));
+    // generous slack: the rays' screen points are formed by other (bit-exact) operations than the corners here, and
+    // differ from them by rounding only
+    const double sinT = sqrt(s2) * (1.0 + 1e-6) + 1e-9;
+    T.sinT = sinT;
+    T.cosT = sqrt(fmax(0.0, 1.0 - sinT * sinT));
+    T.ok = tt > 0 && tt < 1e300 && sinT < 0.5;  // (false for NaN)
+    if (!T.ok) return -1;
+
+    const float4v *groups = (const float4v *)((const char *)ldsGeom + P.listGroupsOff);
+    const float4v *members = (const float4v *)((const char *)ldsGeom + P.listMembersOff);
+    const unsigned short *shapeOf = (const unsigned short *)((const char *)ldsGeom + P.listShapeOff);
+    const int gs = P.groupSize;
+    int count = 0;
+    for (int g0 = 0; g0 < P.listGroups; g0 += 64) {
+        const int g = g0 + lane;
+        unsigned long long open = __ballot(g < P.listGroups && coneMeetsTile(groups[g < P.listGroups ? g : 0], T));
+        while (open) {
+            const int gOpen = g0 + (int)__builtin_ctzll(open);
+            open &= open - 1;
+            // lane m looks at member m of the group (a group has at most 64 members)
+            bool take = false;
+            unsigned short id = 0xffff;
+            if (lane < gs) {
+                id = shapeOf[gOpen * gs + lane];
+                take = id != 0xffff && coneMeetsTile(members[gOpen * gs + lane], T);
+            }
+            const unsigned long long taken = __ballot(take);
+            const int at = count + (int)__popcll(taken & ((1ull << lane) - 1));
+            if (take && at < kTileListCap) list[at] = id;
+            count += (int)__popcll(taken);
+        }
+    }
+    return count <= kTileListCap ? count : -1;
+}
+
+// Closest hit among the spheres of the lane's list: `len` sphere numbers from pool[pos] on (LDS).  One candidate is
+// parked per lane and the exact test runs, for every lane that has one parked, when some lane needs the slot again
+// or has reached the end of its list -- one code site, shared by lanes whose lists differ.  Spheres are met out of
+// index order: see closestHitGrouped for why the winner does not depend on it.
+__device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx, double sy, double sz, double dx, double dy,
+                                                double dz, int pos, int len, float negThreshold, Hit &h) {
+    const float4v *aos = (const float4v *)ldsGeom;
+    const double4v *geom = (const double4v *)((const char *)ldsGeom + P.exactLdsOffset);
+    const unsigned short *pool = (const unsigned short *)((const char *)ldsGeom + P.listPoolOff);
+    Best closest = {0, -1, -1};
+    const double slackBase = fabs(sx) + fabs(sy) + fabs(sz);
+    const double dd = dx * dx + dy * dy + dz * dz;
+    const double slackScale = dd > 0.99 && dd < 1.01 ? 2e-15 : INFINITY;
+    const float sxf = (float)sx, syf = (float)sy, szf = (float)sz;
+    const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
+    int pending = -1;
+    double4v pendingGeom = {0, 0, 0, 0};
+    while (__ballot(len > 0 || pending >= 0)) {
+        int j = -1;
+        if (len > 0) {
+            const int k = pool[pos];
+            const float4v e = aos[k];
+            // single-precision screen (closestHitScreened's arithmetic): below the threshold = exact discriminant negative
+            const float vx = sxf - e.x, vy = syf - e.y, vz = szf - e.z;
+            float b = vx * dxf;
+            b = __builtin_fmaf(vy, dyf, b);
+            b = __builtin_fmaf(vz, dzf, b);
+            float vv = vx * vx;
+            vv = __builtin_fmaf(vy, vy, vv);
+            vv = __builtin_fmaf(vz, vz, vv);
+            if (!(__builtin_fmaf(b, b, e.w - vv) < negThreshold)) j = k;
+        }
+        ++pos;
+        --len;
+        if (__ballot(pending >= 0 && (j >= 0 || len <= 0))) {
+            if (pending >= 0) {
+#ifdef GRAFT_STAMPS
+                if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 10, 1ull);
+#endif
+                exactSphereLazy(pendingGeom, pending, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
+                pending = -1;
+            }
+        }
+        if (j >= 0) {
+            pending = j;
+            pendingGeom = geom[j];
+        }
+    }
+    finishBest(closest, sx, sy, sz, dx, dy, dz, h);
+}
+
 // fresnel() of the reference, mainTracing.c:273-294, bug for bug: the two indices live in `float`, sinN is
 // rounded to float, and the double result is truncated to int, so the weight is 0 unless it is exactly 1.
 // Float division and multiplication are done through double (exact product / correctly rounded quotient, then

@@ -46,7 +46,8 @@ namespace {
 // 3 = two-level screens per ray family (cones for primary and shadow rays, balls for the rest; LDS only),
 // 4 = large scenes: three-level screens per ray family (an entry per 8 groups on top), the cone families' member
 //     sections left in global memory;
-// 5 = level 4 with a uniform grid walked lane by lane in place of the ball family (closestHitGrid).
+// 5 = level 4 with a uniform grid walked lane by lane in place of the ball family (closestHitGrid);
+// 6 = candidate lists: per tile for primary rays, per (sphere, light) for shadow rays (closestHitLists).
 // LDSGEOM: the table the hot loop reads (screen table, or the doubles when SCREEN == 0) is staged in LDS.
 // EXACTLDS (SCREEN > 0 only): the exact doubles are staged in LDS as well, behind the screen table; otherwise the
 // rare exact tests read them from global memory.
@@ -54,10 +55,14 @@ namespace {
 // per-lane stack holds a tree walk (wider entries) instead of a chain.
 // MANYCURSORS: tickets come from kCursors counters instead of one (launches of cheap tiles, see below).  A
 // separate instantiation because the expensive-tile kernels lose 1-3 % to any change of this code (measured).
-template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS>
+// MIRRORS: some shape reflects (or is transparent): a shaded hit may have children, so the lane keeps a stack of
+// levels.  Without it (the reference only recurses `if (reflectivity > 0 && shouldReflect == 1)`, mainTracing.c:330,
+// or for a transparent shape, :347) a ray's value is its hit's own shading and goes straight into the pixel's sum.
+template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS, bool MIRRORS = true>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
+    static_assert(MIRRORS || !TRANSP, "the tree walk needs the stack");
     if (LDSGEOM) {
-        if (SCREEN >= 4) {
+        if (SCREEN == 4 || SCREEN == 5) {
             float *dst = (float *)ldsGeom;
             for (int i = threadIdx.x; i < P.ldsHeadFloats; i += blockDim.x) dst[i] = P.geomF[i];
             float *tail = dst + 4 * (size_t)P.ballMembersLds;
@@ -85,9 +90,14 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     const unsigned long long stampBegin = clock64();
 #endif
 
+    // SCREEN == 6: where the wave's tile list starts in the list pool (in LDS, one list per wave of the workgroup) and
+    // how long the current tile's is (kListAll: every sphere)
+    const int tileListPos = SCREEN == 6 ? ((P.listTileOff - P.listPoolOff) >> 1) + (int)(threadIdx.x >> 6) * kTileListCap : 0;
+    int tileListLen = 0;
+
     // rayIntersectAvoid for one ray per lane (mainTracing.c:128-153): picks the walk the job was built for; returns
-    // how many shapes the ray's avoid list removes from the brute-force count
-    auto closest = [&](const double o[3], const double d[3], int mode, int li, int depth, double tLimit, Hit &h) -> unsigned {
+    // how many shapes the ray's avoid list removes from the brute-force count.  `from`: the shape a shadow ray starts on.
+    auto closest = [&](const double o[3], const double d[3], int mode, int li, int depth, int from, double tLimit, Hit &h) -> unsigned {
         int avoidShape = -1;
         const unsigned char *avoidRow = nullptr;
         unsigned avoided = 0;
@@ -102,7 +112,18 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             const bool tame = s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001;
             if (tame && (SCREEN == 1 || s1 < (SCREEN >= 3 ? P.familyScale : 1e5))) {
                 const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
-                if (SCREEN >= 3) {
+                if (SCREEN == 6) {
+                    // the lane's list: the occluders of (sphere the ray starts on, light), or what the tile can see
+                    int pos = tileListPos, len = tileListLen;
+                    if (mode == M_SHADOW) {
+                        const unsigned *index = (const unsigned *)((const char *)ldsGeom + P.listIndexOff);
+                        const unsigned w = index[from * P.numLights + li];
+                        pos = (int)(w & 0xfffffu);
+                        len = (int)(w >> 20);
+                    }
+                    if (len == (int)kListAll) { pos = 0; len = P.numSpheres; }  // (the pool starts with every sphere)
+                    closestHitLists(P, o[0], o[1], o[2], d[0], d[1], d[2], pos, len, negThreshold, h);
+                } else if (SCREEN >= 3) {
                     // which fixed point the ray's line passes through decides the table it is screened with
                     int family = P.ballFamily;
                     if (mode == M_SHADOW) family = P.lightFamilyBase + li;
@@ -181,6 +202,17 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         const bool inside = ix < P.nCols && by < P.bandRows;
 
         const ConstDoubles cam = cameraView(P);
+        if (SCREEN == 6) {  // what this tile's primary rays can see, worked out once by all lanes together
+            const int ix0 = tx * kTile, ix1 = min(ix0 + kTile, P.nCols) - 1;
+            const int iy0 = P.row0 + ty * kTile, iy1 = P.row0 + min(ty * kTile + kTile, P.bandRows) - 1;
+            // samples lie at the pixel's offsets plus 0 (the mask ray) .. numPasses sub-steps (mainTracing.c:405-406)
+            const double spanX = P.aliasing ? cam[CAM_SUBX] * (double)P.numPasses : 0.0;
+            const double spanY = P.aliasing ? cam[CAM_SUBY] * (double)P.numPasses : 0.0;
+            const int found = buildTileList(P, cam, P.colOff[ix0] + fmin(spanX, 0.0), P.colOff[ix1] + fmax(spanX, 0.0),
+                                            P.rowOff[iy0] + fmin(spanY, 0.0), P.rowOff[iy1] + fmax(spanY, 0.0),
+                                            (unsigned short *)((char *)ldsGeom + P.listTileOff) + (threadIdx.x >> 6) * kTileListCap);
+            tileListLen = found < 0 ? (int)kListAll : found;
+        }
         double acc[3] = {cam[CAM_BACKGROUND], cam[CAM_BACKGROUND + 1], cam[CAM_BACKGROUND + 2]};  // mainTracing.c:395
         int firstIdx = -1;
         if (inside) {
@@ -194,8 +226,9 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             // One entry per shaded hit whose children are still being traced: sum so far [3], tint [3], wRefl,
             // and with TRANSP: wRefr, origin [3] and direction [3] of the refraction ray.  Flags: see F_*.
             constexpr int kEntry = TRANSP ? 14 : 7;
-            double stk[kMaxDepth * kEntry];
-            unsigned char flags[kMaxDepth];
+            constexpr int kLevels = MIRRORS ? kMaxDepth : 1;  // (without mirrors nothing is ever pushed)
+            double stk[kLevels * kEntry];
+            unsigned char flags[kLevels];
             int rayReflects = 1;               // shouldReflect of the ray being traced (mainTracing.c:300)
             double tLimit = INFINITY;          // shadow rays: ray parameter of the light (see closestHitGrid)
 
@@ -264,7 +297,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 const unsigned long long stamp0 = clock64();
 #endif
                 Hit h;
-                const unsigned avoided = closest(o, d, mode, li, depth, mode == M_SHADOW ? tLimit : INFINITY, h);
+                const unsigned avoided = closest(o, d, mode, li, depth, hitIdx, mode == M_SHADOW ? tLimit : INFINITY, h);
                 tracedCount++;
                 if (mode != M_SHADOW) {  // (a hit's shadow rays are booked when it is found)
                     rayCount++;
@@ -308,7 +341,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         din[0] = d[0]; din[1] = d[1]; din[2] = d[2];
                         nrm[0] = nrm[1] = nrm[2] = 0;
                         const double *g = (LDSGEOM && SCREEN == 0) ? (const double *)ldsGeom
-                                          : EXACTLDS ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
+                                          : (EXACTLDS || SCREEN == 6) ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
                         if (h.kind == GRAFT_SPHERE) {  // shapes.c:69-71
                             const double *c = g + 4 * (size_t)h.slot;
                             unit3(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
@@ -376,7 +409,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                             light[c] = litW * t;
                         }
                     }
-                    const bool mirror = m.reflectivity > 0 && rayReflects == 1;   // :330
+                    const bool mirror = MIRRORS && m.reflectivity > 0 && rayReflects == 1;   // :330
                     const bool glass = TRANSP && m.transparency > 0;               // :347, :355
                     const double wDiff = (1 - m.ambientLight) * (1 - m.reflectivity) * (1 - m.transparency);
                     double wRefl = (1 - m.ambientLight) * m.reflectivity, wRefr = 0;
@@ -459,7 +492,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 GRAFT_STAGE(1);  // shading of a finished hit
                 if (unwind) {  // a ray's value v is known: hand it up the tree, innermost first (:338, :363-369)
                     bool launched = false;
-                    while (sp > 0 && !launched) {
+                    while (MIRRORS && sp > 0 && !launched) {
                         double *lv = stk + kEntry * (sp - 1);
                         const unsigned char fl = flags[sp - 1];
                         if (fl & F_MIRROR_PENDING) {  // v is the mirror child's value
@@ -688,39 +721,54 @@ void readSettingsOnce() {
     if (gSettingsRead) return;
     gSettingsRead = true;
     if (const char *e = getenv("GRAFT_SCREEN"))
-        if (e[0] >= '0' && e[0] <= '5' && !e[1]) gSettings.screenCap = e[0] - '0';
+        if (e[0] >= '0' && e[0] <= '0' + kMaxScreen && !e[1]) gSettings.screenCap = e[0] - '0';
     if (const char *e = getenv("GRAFT_GROUP")) gSettings.groupSize = atoi(e);
     if (const char *e = getenv("GRAFT_PER_TICKET")) gSettings.tilesPerTicket = atoi(e) > 0 ? atoi(e) : 0;
 }
 
 typedef void (*TraceFn)(const TraceParams);
 
+// (GRAFT_DEV_KERNELS: a development build that only holds the kernels of the measured workloads -- seconds to
+// compile instead of minutes; every other job is refused.)
 template <int A, bool M>
-TraceFn pickKernelA(bool lds, int screen, bool exactLds) {
+TraceFn pickKernelA(bool lds, int screen, bool exactLds, bool mirrors) {
+#ifdef GRAFT_DEV_KERNELS
+    if (A != 0 || !lds) return nullptr;
+    if (screen == 6) return traceKernel<0, true, 6, false, false, M, false>;
+    if (screen == 5) return traceKernel<0, true, 5, false, false, M>;
+    if (screen == 3 && exactLds) return mirrors ? traceKernel<0, true, 3, true, false, M> : traceKernel<0, true, 3, true, false, M, false>;
+    if (screen == 0) return traceKernel<0, true, 0, false, false, M>;
+    return nullptr;
+#else
     if (!lds) return screen == 2 ? traceKernel<A, false, 2, false, false, M> : screen == 1 ? traceKernel<A, false, 1, false, false, M> : traceKernel<A, false, 0, false, false, M>;
     if (screen == 0) return traceKernel<A, true, 0, false, false, M>;
     if (screen == 1) return exactLds ? traceKernel<A, true, 1, true, false, M> : traceKernel<A, true, 1, false, false, M>;
     if (screen == 2) return exactLds ? traceKernel<A, true, 2, true, false, M> : traceKernel<A, true, 2, false, false, M>;
-    if (screen == 3) return exactLds ? traceKernel<A, true, 3, true, false, M> : traceKernel<A, true, 3, false, false, M>;
+    if (screen == 3 && mirrors) return exactLds ? traceKernel<A, true, 3, true, false, M> : traceKernel<A, true, 3, false, false, M>;
+    if (screen == 3) return exactLds ? traceKernel<A, true, 3, true, false, M, false> : traceKernel<A, true, 3, false, false, M, false>;
     if (screen == 4) return traceKernel<A, true, 4, false, false, M>;
-    return traceKernel<A, true, 5, false, false, M>;
+    if (screen == 5) return traceKernel<A, true, 5, false, false, M>;
+    return traceKernel<A, true, 6, false, false, M, false>;  // (packJob gives level 6 to scenes without mirrors only)
+#endif
 }
 
 // Scenes with a transparent shape run the tree-walk kernels, built only for the general avoid mode, screen
 // levels 0 and 1, and exact doubles in global memory (the jobs are normalised to that in packJob).
 template <bool M>
-TraceFn pickKernelM(int avoidMode, bool lds, int screen, bool exactLds, bool transp) {
+TraceFn pickKernelM(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool mirrors) {
+#ifndef GRAFT_DEV_KERNELS
     if (transp) {
         if (lds) return screen ? traceKernel<2, true, 1, false, true, M> : traceKernel<2, true, 0, false, true, M>;
         return screen ? traceKernel<2, false, 1, false, true, M> : traceKernel<2, false, 0, false, true, M>;
     }
-    return avoidMode == 0 ? pickKernelA<0, M>(lds, screen, exactLds)
-         : avoidMode == 1 ? pickKernelA<1, M>(lds, screen, exactLds) : pickKernelA<2, M>(lds, screen, exactLds);
+#endif
+    return avoidMode == 0 ? pickKernelA<0, M>(lds, screen, exactLds, mirrors)
+         : avoidMode == 1 ? pickKernelA<1, M>(lds, screen, exactLds, mirrors) : pickKernelA<2, M>(lds, screen, exactLds, mirrors);
 }
 
-TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool manyCursors) {
-    return manyCursors ? pickKernelM<true>(avoidMode, lds, screen, exactLds, transp)
-                       : pickKernelM<false>(avoidMode, lds, screen, exactLds, transp);
+TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool mirrors, bool manyCursors) {
+    return manyCursors ? pickKernelM<true>(avoidMode, lds, screen, exactLds, transp, mirrors)
+                       : pickKernelM<false>(avoidMode, lds, screen, exactLds, transp, mirrors);
 }
 
 }  // namespace
@@ -831,7 +879,8 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     // cheap tiles (few samples per pixel) are drawn several at a time and from several counters
     const int samples = P.aliasing ? P.numPasses * P.numPasses : 1;
     const bool manyCursors = samples < 4;
-    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, manyCursors);
+    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, job->mirrors, manyCursors);
+    if (!fn) return fail(GRAFT_ERR_UNSUPPORTED, "this development build holds no kernel for the job");
     if (job->lds && std::find(D->configured.begin(), D->configured.end(), (const void *)fn) == D->configured.end()) {
         // more dynamic LDS than the default limit: raised once per kernel and device, when the kernel is first used
         HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
@@ -906,7 +955,7 @@ GRAFT_API int graftDiagnosticSet(int which, int value) {
     readSettingsOnce();
     switch (which) {
         case GRAFT_DIAG_SCREEN_CAP:
-            if (value < 0 || value > 5) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: screen cap %d", value);
+            if (value < 0 || value > kMaxScreen) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: screen cap %d", value);
             gSettings.screenCap = value;
             return GRAFT_OK;
         case GRAFT_DIAG_GROUP_SIZE:

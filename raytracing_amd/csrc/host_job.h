@@ -19,7 +19,7 @@ namespace graft {
 
 // Diagnostic settings (A/B timing and the tests that run every screen level).  They never change a result.
 struct Settings {
-    int screenCap = 5;       // highest screen level a job may use
+    int screenCap = kMaxScreen;  // highest screen level a job may use
     int groupSize = 0;       // spheres per group of the two-level screens, 0 = chosen per scene
     int tilesPerTicket = 0;  // tiles a wave draws at once, 0 = chosen per launch
 };
@@ -55,6 +55,13 @@ struct TableCache {
         TwoLevelTable table;
     };
     std::list<Cone> cones;  // a list: references handed out stay valid while others are added
+    struct Occluders {      // occluder lists of one light (packLightLists)
+        double light[3], scale;
+        std::vector<unsigned char> avoid;  // the light's avoid row (empty: nothing avoided)
+        bool ok;
+        LightLists lists;
+    };
+    std::list<Occluders> occluders;
     unsigned long long builds = 0;  // tables built so far (tests and the bench read it through the diagnostics getter)
 
     void reset(const std::vector<double> &s, int g) {
@@ -63,9 +70,26 @@ struct TableCache {
         haveBalls = ballsOk = false;
         haveGrid = gridOk = false;
         cones.clear();
+        occluders.clear();
     }
-    void makeRoom(size_t wanted) {  // call before a round of cone() calls, never between them
+    void makeRoom(size_t wanted) {  // call before a round of cone() / occluderLists() calls, never between them
         if (cones.size() + wanted > 32) cones.clear();
+        if (occluders.size() + wanted > 32) occluders.clear();
+    }
+    const Occluders &occluderLists(const double light[3], double scale, const unsigned char *avoidRow, size_t n) {
+        for (Occluders &o : occluders) {
+            if (o.light[0] != light[0] || o.light[1] != light[1] || o.light[2] != light[2] || o.scale != scale) continue;
+            bool same = avoidRow ? o.avoid.size() == n && memcmp(o.avoid.data(), avoidRow, n) == 0 : o.avoid.empty();
+            if (same) return o;
+        }
+        occluders.emplace_back();
+        Occluders &o = occluders.back();
+        o.light[0] = light[0]; o.light[1] = light[1]; o.light[2] = light[2];
+        o.scale = scale;
+        if (avoidRow) o.avoid.assign(avoidRow, avoidRow + n);
+        o.ok = packLightLists(sph, light, scale, avoidRow, o.lists);
+        builds++;
+        return o;
     }
     const TwoLevelTable &cone(const double apex[3], double scale) {
         for (Cone &c : cones)
@@ -124,6 +148,81 @@ inline bool packLevel5(TableCache &cache, const std::vector<double> &sph, size_t
     table.insert(table.end(), tail.begin(), tail.end());
     inter.swap(table);
     interShape.swap(shapes);
+    return true;
+}
+
+// Level 6 (closestHitLists): every primary ray looks only at the spheres its TILE can see (a list the wave builds per
+// tile from the camera's two-level cone table), every shadow ray only at the spheres that can lie between the sphere
+// it starts on and its light (lists built here, per light).  Builds the LDS image described at TraceParams::listGroups
+// and sets the launch parameters; returns false when the job does not qualify or the image does not fit.
+inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const GraftView *view,
+                       const std::vector<DevLight> &lights, const std::vector<unsigned char> &mask, int nS, double scale,
+                       std::vector<float> &image, TraceParams &P, size_t &ldsBytes, int &block) {
+    const size_t n = sph.size() / 4, nL = lights.size();
+    if (n > 65535 || n * nL > (1u << 22)) return false;
+    // the tile's bounding cone is drawn around the rays of its first and last columns and rows
+    for (int i = 1; i < view->nCols; ++i)
+        if (!(view->colOffsets[i] >= view->colOffsets[i - 1])) return false;
+    for (int i = 1; i < view->nRows; ++i)
+        if (!(view->rowOffsets[i] >= view->rowOffsets[i - 1])) return false;
+    const TwoLevelTable &cam = cache.cone(view->camPos, scale);
+    const size_t gs = (size_t)cam.kGroup, G = cam.memberShape.size() / gs;
+    std::vector<const LightLists *> lists;
+    for (size_t i = 0; i < nL; ++i) {
+        const unsigned char *row = lights[i].avoidNum > 0 ? mask.data() + i * (size_t)nS : nullptr;
+        const TableCache::Occluders &o = cache.occluderLists(lights[i].loc, scale, row, n);
+        if (!o.ok) return false;
+        lists.push_back(&o.lists);
+    }
+    auto up = [](size_t x, size_t a) { return (x + a - 1) / a * a; };
+    const size_t oAos = 0, oExact = up(oAos + 16 * n, 32), oGroups = up(oExact + 32 * n, 16), oMembers = oGroups + 16 * G,
+                 oShape = oMembers + 16 * G * gs, oIndex = up(oShape + 2 * G * gs, 4), oPool = oIndex + 4 * n * nL;
+    size_t poolEntries = n;  // the list of all spheres comes first
+    std::vector<size_t> base(nL);
+    for (size_t i = 0; i < nL; ++i) { base[i] = poolEntries; poolEntries += lists[i]->pool.size(); }
+    if (poolEntries >= (1u << 20)) return false;
+    const size_t blob = up(oPool + 2 * poolEntries, 16);
+    block = 0;
+    for (int b = kSmallBlock; b <= kLargeBlock; b *= 2) {
+        const size_t total = blob + (size_t)(b / 64) * 2 * kTileListCap;
+        const size_t limit = b == kSmallBlock ? kLdsSmall : b == 2 * kSmallBlock ? 2 * kLdsSmall : kLdsMax;
+        if (total <= limit) { block = b; ldsBytes = total; break; }
+    }
+    if (!block) return false;
+    std::vector<unsigned char> lds(blob, 0);
+    for (size_t k = 0; k < n; ++k) {
+        float e[4] = {(float)sph[4 * k], (float)sph[4 * k + 1], (float)sph[4 * k + 2], 0.0f};
+        if (!screenRho(&sph[4 * k], sph[4 * k + 3], e[3])) return false;
+        memcpy(&lds[oAos + 16 * k], e, sizeof e);
+    }
+    memcpy(&lds[oExact], sph.data(), 32 * n);
+    std::vector<float> plain;
+    unpackEntries(cam.entries, 0, G, plain);
+    memcpy(&lds[oGroups], plain.data(), 16 * G);
+    unpackEntries(cam.entries, (size_t)cam.memberBase, G * gs, plain);
+    memcpy(&lds[oMembers], plain.data(), 16 * G * gs);
+    for (size_t m = 0; m < G * gs; ++m) {
+        const unsigned short id = cam.memberShape[m] < 0 ? (unsigned short)0xffff : (unsigned short)cam.memberShape[m];
+        memcpy(&lds[oShape + 2 * m], &id, 2);
+    }
+    for (size_t k = 0; k < n; ++k)
+        for (size_t i = 0; i < nL; ++i) {
+            unsigned w = lists[i]->index[k];
+            if ((w >> 20) != kListAll) w += (unsigned)base[i];  // (offsets stay below 2^20: checked above)
+            memcpy(&lds[oIndex + 4 * (k * nL + i)], &w, 4);
+        }
+    for (size_t k = 0; k < n; ++k) {
+        const unsigned short id = (unsigned short)k;
+        memcpy(&lds[oPool + 2 * k], &id, 2);
+    }
+    for (size_t i = 0; i < nL; ++i)
+        if (!lists[i]->pool.empty()) memcpy(&lds[oPool + 2 * base[i]], lists[i]->pool.data(), 2 * lists[i]->pool.size());
+    image.assign(blob / 4, 0.0f);
+    memcpy(image.data(), lds.data(), blob);
+    P.exactLdsOffset = (int)oExact;
+    P.listGroups = (int)G;
+    P.listGroupsOff = (int)oGroups; P.listMembersOff = (int)oMembers; P.listShapeOff = (int)oShape;
+    P.listIndexOff = (int)oIndex; P.listPoolOff = (int)oPool; P.listTileOff = (int)blob;
     return true;
 }
 
@@ -210,6 +309,11 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     cam.lrDen = cam.lrVec[0] * cam.lrVec[0] + cam.lrVec[1] * cam.lrVec[1] + cam.lrVec[2] * cam.lrVec[2];
     cam.udDen = cam.udVec[0] * cam.udVec[0] + cam.udVec[1] * cam.udVec[1] + cam.udVec[2] * cam.udVec[2];
     cam.subStepX = view->subStepX; cam.subStepY = view->subStepY;
+    for (int c = 0; c < 3; ++c) {
+        cam.toScreen[c] = cam.screenCenter[c] - cam.camPos[c];
+        cam.lrUnit[c] = cam.lrVec[c] / sqrt(cam.lrDen);
+        cam.udUnit[c] = cam.udVec[c] / sqrt(cam.udDen);
+    }
     P.projectionType = view->projectionType; P.aliasing = view->aliasing ? 1 : 0;
     P.numPasses = view->numPasses; P.maxDepth = scene->maxDepth;
     P.numShapes = nS; P.numLights = nL; P.numRuns = (int)runs.size(); P.numSpheres = (int)(sph.size() / 4);
@@ -301,7 +405,21 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
             scale = fmax(scale, fabs(sph[4 * k]) + fabs(sph[4 * k + 1]) + fabs(sph[4 * k + 2]) + sqrt(sph[4 * k + 3]));
         for (const auto &a : apexes) scale = fmax(scale, fabs(a[0]) + fabs(a[1]) + fabs(a[2]));
         if (scale > 0 && scale < kGroupScale) scale = fmax(1.0, exp2(ceil(log2(scale))));  // (NaN stays NaN)
-        if (!apexes.empty() && scale < kGroupScale) {  // (NaN fails the comparison)
+        size_t ldsBytes6 = 0;
+        int block6 = 0;
+        if (screenCap >= 6 && lightBase == 1 && scale < kGroupScale && !mirrors) {
+            cache.makeRoom(apexes.size());
+            std::vector<float> image6;
+            if (packLevel6(cache, sph, view, lights, mask, nS, scale, image6, P, ldsBytes6, block6)) {
+                screen = 6;
+                tableF.swap(image6);
+                memberShape.clear();
+                P.familyScale = scale;
+                J.ldsBytes = ldsBytes6;
+                J.block = block6;
+            }
+        }
+        if (screen != 6 && !apexes.empty() && scale < kGroupScale) {  // (NaN fails the comparison)
             std::vector<const TwoLevelTable *> fam;
             cache.makeRoom(apexes.size());
             for (size_t f = 0; f < apexes.size(); ++f) fam.push_back(&cache.cone(apexes[f].data(), scale));
@@ -392,8 +510,13 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     const size_t tableBytes = screen >= 4 ? sizeof(float) * ((size_t)P.ldsHeadFloats + P.ldsTailFloats)
                             : screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)(P.geomDoubles + kGeomPad);
     const size_t exactBytes = sizeof(double) * (size_t)P.geomDoubles;
-    J.lds = tableBytes <= kLdsMax;
     J.transp = transparent;
+    if (screen == 6) {  // (LDS image, workgroup size and the offset of the exact doubles: packLevel6)
+        J.lds = true;
+        J.exactLds = false;
+        return GRAFT_OK;
+    }
+    J.lds = tableBytes <= kLdsMax;
     J.exactLds = !transparent && J.lds && screen && screen < 4 && ((tableBytes + 31) & ~(size_t)31) + exactBytes <= kLdsMax;
     P.exactLdsOffset = (int)((tableBytes + 31) & ~(size_t)31);
     J.ldsBytes = !J.lds ? 0 : J.exactLds ? P.exactLdsOffset + exactBytes : tableBytes;

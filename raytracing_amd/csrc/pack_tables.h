@@ -404,6 +404,108 @@ inline bool packGrid(const std::vector<double> &sph, GridTable &T) {
     return true;
 }
 
+// The entries of a two-level table as plain {x, y, z, w} quadruples (entry e at 4 e), for code in which every lane
+// reads an entry of its own: the tile-list build of closestHitLists.
+inline void unpackEntries(const std::vector<float> &packed, size_t first, size_t count, std::vector<float> &out) {
+    out.resize(4 * count);
+    for (size_t i = 0; i < count; ++i) {
+        const size_t e = first + i;
+        const float *pair = packed.data() + 16 * (e / 4) + 8 * ((e % 4) >> 1);
+        const int h = (int)(e & 1);
+        out[4 * i] = pair[0 + h]; out[4 * i + 1] = pair[2 + h]; out[4 * i + 2] = pair[4 + h]; out[4 * i + 3] = pair[6 + h];
+    }
+}
+
+// Occluder lists (closestHitLists): for one light and every sphere k, the spheres a shadow ray that STARTS ON sphere k
+// towards the light can meet before the light.  Seen from the light, sphere j is a cone (u_j, alpha_j) as in
+// packConeTable, widened by the same margin m_j (a line through the light that misses the widened cone has a
+// negative double-precision discriminant against sphere j in the reference, with room to spare).  A shadow ray whose
+// origin p lies on sphere k (p = s + t d as sphereIntersect forms it, shapes.c:67-68: | |p - c|^2 - r^2 | is the
+// rounding error of the discriminant, below 2e-15 S^2 for coordinates below S, so p is within 1e-13 S^2 / r of the
+// surface; then nudged 1e-6 along the ray, mainTracing.c:163-167) runs along the line through p and the light, and
+// the direction from the light to p lies inside the cone of sphere k grown by grow_k = 1e-9 S + 3e-6 + 1e-13 S^2 / r_k
+// (half-angle B_k).  So sphere j can be met only if
+//   * the cones (u_j, A_j = alpha_j + m_j) and (u_k, B_k) overlap ON THE SAME SIDE of the light -- a sphere the line
+//     meets on the far side of the light is met beyond the light, and the caller (lighting(), mainTracing.c:210-215)
+//     treats "closest hit beyond the light" exactly like "no hit"; and
+//   * sphere j is not wholly farther from the light than every point of sphere k (dist_j - r_j > dist_k + r_k +
+//     slack): every point of the ray between p and the light is at most |p - L| from the light, and beyond the light
+//     the ray moves away from such a sphere (its direction makes less than a right angle with u_j's opposite).
+// A sphere with the light inside, on or near it (cone wider than kWide) is on every list of that light, and a sphere
+// k whose own cone is that wide gets the list of ALL spheres, so hits at or next to the light's position are found
+// with the reference's arithmetic as ever.  What is closest among the listed spheres is then either the reference's
+// closest hit (if that lies before the light) or lies beyond the light whenever the reference's does.
+// Shapes on the light's avoid list (mainTracing.c:134, :210) are left out here, once, instead of being compared
+// per ray.  Entries are sphere numbers (16 bits); list (k) = pool[index[k] & 0xfffff ...], length index[k] >> 20,
+// length kListAll standing for "every sphere".  Returns false when the scene does not qualify.
+constexpr unsigned kListAll = 4095;
+struct LightLists {
+    std::vector<unsigned> index;        // per sphere: offset into pool | length << 20
+    std::vector<unsigned short> pool;
+};
+
+inline bool packLightLists(const std::vector<double> &sph, const double light[3], double scale,
+                           const unsigned char *avoidRow, LightLists &T) {
+    const int n = (int)(sph.size() / 4);
+    if (n > 65535) return false;
+    const double eBound = 1e-13 * (4 * scale) * (4 * scale);
+    const double kWide = 1.4;
+    std::vector<double> dir(3 * (size_t)n), dist(n), rad(n), grow(n), cosA(n), sinA(n), cosB(n), sinB(n);
+    std::vector<unsigned char> wideA(n), wideB(n);
+    for (int k = 0; k < n; ++k) {
+        const double *c = &sph[4 * (size_t)k];
+        const double w[3] = {c[0] - light[0], c[1] - light[1], c[2] - light[2]};
+        const double len = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const double r = sqrt(c[3]);
+        dist[k] = len;
+        rad[k] = r;
+        grow[k] = 1e-9 * scale + 3e-6 + 1e-13 * scale * scale / r;  // (r = 0: infinite, the sphere lists everything)
+        wideA[k] = wideB[k] = 1;
+        cosA[k] = cosB[k] = -1; sinA[k] = sinB[k] = 0;
+        dir[3 * (size_t)k] = 1; dir[3 * (size_t)k + 1] = 0; dir[3 * (size_t)k + 2] = 0;
+        if (!(len > 0) || !std::isfinite(len) || !std::isfinite(r)) continue;  // always listed, lists everything
+        for (int a = 0; a < 3; ++a) dir[3 * (size_t)k + a] = w[a] / len;
+        if (len > r * (1 + 1e-9) + 1e-9 * scale) {
+            const double A = asin(r / len) + 1.01 * sqrt(eBound) / len + 1e-7;
+            if (A < kWide) { wideA[k] = 0; cosA[k] = cos(A); sinA[k] = sin(A); }
+        }
+        if (len > (r + grow[k]) * (1 + 1e-9) + 1e-9 * scale) {
+            const double B = asin((r + grow[k]) / len) + 1e-7;
+            if (B < kWide) { wideB[k] = 0; cosB[k] = cos(B); sinB[k] = sin(B); }
+        }
+    }
+    T.index.assign(n, 0);
+    T.pool.clear();
+    std::vector<unsigned short> list;
+    for (int k = 0; k < n; ++k) {
+        list.clear();
+        bool all = wideB[k] != 0;
+        const double *uk = &dir[3 * (size_t)k];
+        const double reach = (dist[k] + rad[k] + grow[k]) * (1 + 1e-12);
+        for (int j = 0; j < n && !all; ++j) {
+            if (avoidRow && avoidRow[j]) continue;
+            if (!wideA[j]) {
+                const double *uj = &dir[3 * (size_t)j];
+                const double c = uj[0] * uk[0] + uj[1] * uk[1] + uj[2] * uk[2];
+                // cos(A_j + B_k); both angles are below kWide, so the sum is below pi and the cosine decreases
+                if (c < cosA[j] * cosB[k] - sinA[j] * sinB[k] - 1e-12) continue;
+                // wholly behind sphere k as seen from the light (and within a right angle of it, see above)
+                if (dist[j] - rad[j] > reach && c > 0.5 && cosA[j] > 0.9 && cosB[k] > 0.9) continue;
+            }
+            list.push_back((unsigned short)j);
+            if (list.size() >= kListAll) all = true;
+        }
+        if (all) {
+            T.index[k] = kListAll << 20;
+        } else {
+            if (T.pool.size() + list.size() >= (1u << 20)) return false;
+            T.index[k] = (unsigned)T.pool.size() | ((unsigned)list.size() << 20);
+            T.pool.insert(T.pool.end(), list.begin(), list.end());
+        }
+    }
+    return true;
+}
+
 // Interleave the tables of several ray families block by block (a block = 4 packed entries = 64 bytes): block b of
 // family f lands at float4 index 4 * (b * families + f), and the shape index of member entry i at i * families + f.
 // A lane then reads a block with one address and four fixed offsets, and lanes of one wave that trace rays of

@@ -12,6 +12,7 @@ namespace graft {
 
 
 constexpr int kTile = 8;            // 8x8 pixels = one wave64
+constexpr int kMaxScreen = 6;       // highest screen level (TraceParams, traceKernel's SCREEN)
 constexpr int kMaxDepth = 12;       // levels of the reflection chain kept per lane
 constexpr int kSmallBlock = 256;    // scenes whose geometry fits a quarter of the LDS
 #ifndef GRAFT_LARGE_BLOCK
@@ -24,6 +25,7 @@ constexpr int kCursors = 16;        // ticket counters of the many-counter kerne
 constexpr int kCursorStride = 32;   // ... one per 128-byte line
 constexpr size_t kLdsSmall = 36 * 1024;
 constexpr size_t kLdsMax = 152 * 1024;
+constexpr int kTileListCap = 128;   // entries of a wave's tile list (closestHitLists); longer lists fall back to all spheres
 
 struct DevRun {  // shapes [firstShape, firstShape+count) are all of `kind`; their geometry starts at slot
     int kind, firstShape, count, slot;
@@ -55,16 +57,20 @@ struct DevCamera {
     double lrDen, udDen;  // dir.dir of lrVec / udVec as getNewPoint forms it (mainTracing.c:107)
     double background[3];
     double subStepX, subStepY;
+    // for the cone that bounds a tile's primary rays (closestHitLists): screenCenter - camPos and the unit vectors
+    // along lrVec and udVec; the point of world offsets (x, y) lies at toScreen + x lrUnit + y udUnit from the camera
+    double toScreen[3], lrUnit[3], udUnit[3];
 };
 
 // The same block seen as doubles in the constant address space: loads through this view are scalar loads whatever
 // else the kernel stores to global memory (the block is written before the launch and never by a kernel).
 typedef const double __attribute__((address_space(4))) *ConstDoubles;
 enum { CAM_SCREEN = 0, CAM_POS = 3, CAM_VIEW = 6, CAM_LR = 9, CAM_UD = 12, CAM_LRDEN = 15, CAM_UDDEN = 16, CAM_BACKGROUND = 17,
-       CAM_SUBX = 20, CAM_SUBY = 21 };
+       CAM_SUBX = 20, CAM_SUBY = 21, CAM_TOSCREEN = 22, CAM_LRUNIT = 25, CAM_UDUNIT = 28 };
 static_assert(offsetof(DevCamera, camPos) == 8 * CAM_POS && offsetof(DevCamera, udVec) == 8 * CAM_UD &&
               offsetof(DevCamera, lrDen) == 8 * CAM_LRDEN && offsetof(DevCamera, background) == 8 * CAM_BACKGROUND &&
-              offsetof(DevCamera, subStepY) == 8 * CAM_SUBY, "DevCamera layout");
+              offsetof(DevCamera, subStepY) == 8 * CAM_SUBY && offsetof(DevCamera, udUnit) == 8 * CAM_UDUNIT,
+              "DevCamera layout");
 
 // Grid of closestHitGrid, read by scalar loads like the camera block: lo[3], hi[3], cell size[3], 1 / cell size[3].
 struct DevGrid {
@@ -107,6 +113,12 @@ struct TraceParams {
     int gridNx, gridNy, gridNz;
     int gridCellsOff, gridRefsOff, gridAosOff;
     const DevGrid *grid;
+    // SCREEN == 6 (candidate lists, closestHitLists): the LDS image is the first filterFloats floats of geomF, laid out
+    // as {sphere screen table [numSpheres] float4 | exact doubles at exactLdsOffset | camera cone table: listGroups
+    // group entries, listGroups * groupSize member entries (float4 each) and the members' sphere numbers (16 bits) |
+    // occluder-list index [numSpheres][numLights] | list pool (16-bit sphere numbers; the list of all spheres first) |
+    // one tile list of kTileListCap entries per wave of the workgroup}; byte offsets from the start of LDS
+    int listGroups, listGroupsOff, listMembersOff, listShapeOff, listIndexOff, listPoolOff, listTileOff;
     const int *memberShape;    // grouped screen: shape index of every member-table entry, -1 = padding
     const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
     const double *geom;

@@ -58,7 +58,7 @@ def device_count():
 
 
 def set_diagnostic(name, value):
-    """graftDiagnosticSet: "screen_cap" 0..5, "group_size" 0|4..64, "tiles_per_ticket" (A/B timing and tests;
+    """graftDiagnosticSet: "screen_cap" 0..6, "group_size" 0|4..64, "tiles_per_ticket" (A/B timing and tests;
     no setting changes a result).  Returns the previous value."""
     which = _lib.DIAGNOSTICS[name]
     old = lib.graftDiagnosticGet(which)

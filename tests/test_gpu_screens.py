@@ -1,6 +1,8 @@
 """The conservative screens (single-precision per-sphere screen, two-level ball screen, per-family cone screens)
 must never change a result.  Random and adversarial sphere scenes, GPU against the CPU oracle, bit for bit, at
-every screen level (the screen_cap setting, 0..5, caps the level a job may use; 0 is the plain double-precision loop)."""
+every screen level (the screen_cap setting, 0..6, caps the level a job may use; 0 is the plain double-precision loop).
+Level 6 (candidate lists) takes scenes without reflecting shapes seen in perspective; the scenes of the other tests
+mostly have mirrors, so the tests at the end of this file run their shapes again without."""
 import numpy as np
 import pytest
 
@@ -33,7 +35,7 @@ def scene(seed, n, size=(64, 64), lights=3, radius=(5.0, 40.0), box=400.0, refl=
     return rt
 
 
-def check_all_levels(rt, levels=(0, 1, 2, 3, 4, 5)):
+def check_all_levels(rt, levels=(0, 1, 2, 3, 4, 5, 6)):
     want = ob.render(rt, threads=16, want_index=True)
     old = get_diagnostic("screen_cap")
     try:
@@ -207,7 +209,7 @@ def test_groups_of_sixteen_and_other_sizes(gpu):
 
 def test_levels_are_actually_used(gpu):
     """The scenes above must really reach the screens they are meant to test."""
-    def level(rt, cap=5):
+    def level(rt, cap=6):
         old = set_diagnostic("screen_cap", cap)
         try:
             job = rt.create_job()
@@ -216,11 +218,15 @@ def test_levels_are_actually_used(gpu):
             return lv
         finally:
             set_diagnostic("screen_cap", old)
-    assert level(scene(0, 96)) == 3
-    assert [level(scene(0, 96), cap) for cap in (0, 1, 2, 3)] == [0, 1, 2, 3]
-    assert level(scenes.workload("cfg4", 64, 64)) == 3 and level(scenes.workload("cfg3", 64, 64)) == 3
+    assert level(scene(0, 96)) == 6 and level(scene(0, 96, refl=0.5)) == 3
+    assert [level(scene(0, 96), cap) for cap in (0, 1, 2, 3, 5)] == [0, 1, 2, 3, 3]
+    assert level(scenes.workload("cfg4", 64, 64)) == 6 and level(scenes.workload("cfg3", 64, 64)) == 6
+    assert level(scenes.workload("cfg4", 64, 64), 5) == 3 and level(scenes.workload("cfg3", 64, 64), 5) == 3
     assert level(scenes.workload("cfg5", 64, 64)) == 5 and level(scenes.workload("cfg5", 64, 64), 4) == 4
     assert level(large_scene(30, 1500, lights=5)) == 5 and level(large_scene(30, 1500, lights=5), 3) == 2
+    assert level(matte(large_scene(32, 2100, lights=4))) == 5   # its list tables do not fit in LDS
+    assert level(matte(large_scene(33, 600, lights=3))) == 6
+    assert level(scene(11, 130, projection=ORTHOGRAPHIC)) == 3    # no camera to build tile lists around
     assert level(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7)) == 5
     assert level(scene(20, 100, lights=9)) == 2          # too many lights for the family tables
     assert level(scene(1, 40)) == 1                      # too few spheres for grouping
@@ -229,3 +235,110 @@ def test_levels_are_actually_used(gpu):
     rt.shapes[3].transparency = 0.5
     assert level(rt) == 1                                # transparent: tree-walk kernels, per-sphere screen
 
+
+
+# ---- level 6: candidate lists (scenes without reflecting shapes, perspective) -------------------------------------
+
+def matte(rt):
+    """The same scene with every reflectivity set to 0."""
+    for s in rt.shapes[:rt.numShapes]:
+        s.reflectivity = 0.0
+    return rt
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_lists_random_scenes(gpu, seed):
+    check_all_levels(scene(50 + seed, 96 + 40 * seed, lights=1 + seed), levels=(0, 3, 6))
+
+
+def test_lists_supersampled_rotated_zoomed(gpu):
+    check_all_levels(scene(54, 150, passes=3, size=(48, 48)), levels=(0, 6))
+    rt = scene(55, 160, size=(72, 40))
+    rt.rotateView(0.4, [0.0, 1.0, 0.0])
+    rt.rotateView(-0.25, list(rt.lrVec))
+    rt.screenWidth *= 1.1
+    rt.screenHeight *= 0.9
+    check_all_levels(rt, levels=(0, 6))
+    rt.aliasing, rt.numPasses = ANTIALIASING_ON, 2
+    check_all_levels(rt, levels=(0, 6))
+
+
+def test_lists_lights_and_camera_inside_or_on_spheres(gpu):
+    """The camera inside a sphere: that sphere is on every tile's list.  A light inside or on a sphere: that sphere is
+    on every occluder list of the light, and a shadow ray that starts on it may meet any sphere."""
+    rt = scene(56, 100)
+    rt.sphereSetup(90, list(rt.lights[0].loc), 100, [.8, .3, .3], 0.0, 0.1, 1.0, 0.0)          # around light 0
+    rt.sphereSetup(2000, [0, 0, -1256 + 10], 101, [.3, .8, .3], 0.0, 0.1, 1.0, 0.0)             # around the camera
+    rt.sphereSetup(60, [rt.lights[1].loc[0] + 60.0, rt.lights[1].loc[1], rt.lights[1].loc[2]], 102, [.3, .3, .8], 0.0,
+                   0.1, 1.0, 0.0)                                                                # light 1 ON its surface
+    rt.sphereSetup(30, [rt.lights[2].loc[0] + 30.0 * (1 + 1e-7), rt.lights[2].loc[1], rt.lights[2].loc[2]], 103,
+                   [.9, .9, .3], 0.0, 0.1, 1.0, 0.0)                                             # light 2 a hair outside
+    rt.numShapes = 104
+    check_all_levels(rt, levels=(0, 3, 6))
+
+
+def test_lists_avoid_lists(gpu):
+    rt = scene(57, 120, lights=3)
+    lightSetAvoid(rt.lights[0], [rt.shapes[5]], 1)
+    check_all_levels(rt, levels=(0, 6))
+    lightSetAvoid(rt.lights[1], [rt.shapes[7], rt.shapes[70], rt.shapes[7]], 3)
+    check_all_levels(rt, levels=(0, 6))
+
+
+def test_lists_duplicates_and_near_duplicates(gpu):
+    rt = scene(58, 80)
+    for k in range(40):
+        src = rt.shapes[k]
+        eps = [0.0, 0.0, 1e-15, 3e-14, 1e-12, 1e-10, 1e-8][k % 7]
+        c = [src.unif[0] * (1 + eps), src.unif[1] * (1 - eps), src.unif[2] + eps * 100]
+        rt.sphereSetup(src.unif[3] * (1 + (eps if k % 2 else -eps)), c, 80 + k, [.9, .1, .1], 0.0, 0.1, 1.0, 0.0)
+    rt.numShapes = 120
+    check_all_levels(rt, levels=(0, 6))
+
+
+def test_lists_tiny_giant_and_overlapping_spheres(gpu):
+    rt = scene(59, 90, radius=(0.01, 3.0))
+    rt.sphereSetup(5000, [0, 0, 200], 90, [.5, .5, .9], 0.0, 0.1, 1.0, 0.0)      # encloses everything, lights included
+    rt.sphereSetup(1e-3, [10, 10, 50], 91, [1, 1, 1], 0.0, 0.1, 1.0, 0.0)
+    rt.numShapes = 92
+    check_all_levels(rt, levels=(0, 6))
+    rt = scene(60, 140, radius=(60.0, 160.0), box=300.0)                         # every sphere cuts through several others
+    check_all_levels(rt, levels=(0, 3, 6))
+    rt = scene(61, 70)
+    rt.sphereSetup(1e-150, [5, -3, 60], 70, [1, 1, 1], 0.0, 0.1, 1.0, 0.0)
+    rt.sphereSetup(0.0, [-20, 12, 80], 71, [1, 1, 1], 0.0, 0.1, 1.0, 0.0)
+    rt.numShapes = 72
+    check_all_levels(rt, levels=(0, 6))
+
+
+def test_lists_tile_list_overflow_and_wide_views(gpu):
+    """More spheres in a tile's cone than its list holds (a small frame of many spheres): the tile falls back to the
+    list of all spheres; and a view so wide that a tile has no usable bounding cone."""
+    rt2 = scene(62, 700, size=(16, 16), radius=(3.0, 14.0), lights=2)
+    check_all_levels(rt2, levels=(0, 6))
+    rt3 = scene(63, 100, size=(24, 24))
+    rt3.screenWidth = rt3.screenHeight = 40000.0     # 8-pixel tiles span tens of degrees
+    check_all_levels(rt3, levels=(0, 6))
+    rt4 = scene(64, 100, size=(24, 24))
+    rt4.screenWidth = rt4.screenHeight = 3.0         # zoomed far in: most tiles see nothing or one sphere
+    check_all_levels(rt4, levels=(0, 6))
+
+
+def test_lists_seven_lights_and_large_coordinates(gpu):
+    check_all_levels(scene(65, 100, lights=7), levels=(0, 6))
+    rt = scene(66, 100, centre=(1.6e4, 1.5e4, 1.7e4), box=300.0)
+    rt.sceneInitialize([1.6e4, 1.5e4, 1.7e4], 256, 1000)
+    for l in rt.lights[:rt.numLights]:
+        l.loc = [l.loc[0] + 1.6e4, l.loc[1] + 1.5e4, l.loc[2] + 1.7e4]
+    check_all_levels(rt, levels=(0, 3, 6))
+
+
+def test_lists_six_hundred_spheres(gpu):
+    check_all_levels(matte(large_scene(33, 600, lights=3)), levels=(0, 3, 6))
+    old = get_diagnostic("group_size")
+    try:
+        for size in (4, 32):
+            set_diagnostic("group_size", size)
+            check_all_levels(matte(large_scene(33, 600, lights=3)), levels=(6,))
+    finally:
+        set_diagnostic("group_size", old)
