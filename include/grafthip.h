@@ -131,14 +131,15 @@ GRAFT_API const char *graftLastError(void);
 
 /* Diagnostic settings: for A/B timing and for the tests that run every kernel variant.  None of them changes a
  * result.  They start from the environment, which is read ONCE, at the first graftInit or graftDiagnostic* call
- * (GRAFT_SCREEN, GRAFT_GROUP, GRAFT_PER_TICKET); afterwards only graftDiagnosticSet changes them, and
+ * (GRAFT_SCREEN, GRAFT_GROUP, GRAFT_PER_TICKET, GRAFT_RESERVED_CUS); afterwards only graftDiagnosticSet changes them, and
  * graftDiagnosticGet reports the values in force.  A setting applies to jobs created (SCREEN_CAP, GROUP_SIZE) or
  * traces queued (TILES_PER_TICKET) after the call.  (No reference counterpart.) */
 enum {
-    GRAFT_DIAG_SCREEN_CAP = 0,       /* 0..5: highest screen level a job may use (graftJobScreenLevel); default 5 */
+    GRAFT_DIAG_SCREEN_CAP = 0,       /* 0..6: highest screen level a job may use (graftJobScreenLevel); default 6 */
     GRAFT_DIAG_GROUP_SIZE = 1,       /* spheres per group of the two-level screens: 0 = chosen per scene, else 4..64, a multiple of 4 */
     GRAFT_DIAG_TILES_PER_TICKET = 2, /* 8x8 tiles a wave draws from the ticket counters at once: 0 = chosen per launch */
-    GRAFT_DIAG_TABLE_BUILDS = 4      /* read-only: screen tables built so far (shows what a re-render re-used) */
+    GRAFT_DIAG_TABLE_BUILDS = 4,     /* read-only: screen tables built so far (shows what a re-render re-used) */
+    GRAFT_DIAG_RESERVED_CUS = 5      /* CUs a trace's persistent grid leaves free, 0..128; default 0 (graftRenderFrameMulti uses at least 4) */
 };
 GRAFT_API int graftDiagnosticSet(int which, int value);
 GRAFT_API int graftDiagnosticGet(int which); /* -1 for an unknown setting */
@@ -176,7 +177,9 @@ GRAFT_API void graftJobDestroy(GraftJob *job);
 
 /* Which screen the job's kernels use in front of the exact sphere test (diagnostics; no reference counterpart):
  * 0 = none (exact double loop), 1 = single-precision screen per sphere, 2 = two-level ball screen, 3 = two-level
- * screens per ray family, 4 = the same with cone member sections in global memory.  -1 for a null job. */
+ * screens per ray family, 4 = three levels with cone member sections in global memory, 5 = level 4 with a uniform
+ * grid for the rays behind a mirror, 6 = candidate lists (per tile for primary rays, per sphere and light for shadow
+ * rays).  -1 for a null job. */
 GRAFT_API int graftJobScreenLevel(const GraftJob *job);
 
 /* Trace loop rows [row0, row0+nRows) of the job's frame into DEVICE memory: `frame` holds nRows*nCols pixels
@@ -203,8 +206,9 @@ GRAFT_API int graftSynchronize(void);
 GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
                               void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost);
 
-/* graftRenderRows for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
- * that forbid it): no counterpart in the reference.  It calls no hipMalloc, hipFree, hipHostMalloc or other
+/* graftRenderRows for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc): no
+ * counterpart in the reference.  (Not for use under HIP graph capture: the call waits on an event and stages the
+ * upload through one page-locked block, so a captured call could neither be repeated nor replayed.)  It calls no hipMalloc, hipFree, hipHostMalloc or other
  * allocating HIP routine: the device block a trace reads (tables + ticket counters) lives in a static __device__
  * array of GRAFT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends, reached
  * through the address graftInit looked up for that GPU, and the upload goes through a page-locked block graftInit
@@ -230,12 +234,20 @@ GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *v
  * the tracing of the next round's pieces.
  *
  * graftInitDevices binds GPUs 0 .. nDevices-1 (GPU 0 is the root and the device of the single-GPU entry points; it is
- * graftInit(0) when nDevices is 1).  graftFramePieces is the piece list (pure host arithmetic; returns the number of
- * pieces, writes at most `cap`): piece k covers rows [firstRow[k], firstRow[k] + rows[k]) and belongs to GPU
- * owner[k].  graftRenderFrameMulti is graftRenderRows for the whole frame over all bound GPUs, host buffers out;
- * with one GPU bound it IS graftRenderRows. */
+ * graftInit(0) when nDevices is 1); if it fails, no multi-device frame can be started until a later call succeeds.
+ * graftFramePlan is the piece list (pure host arithmetic; returns the number of pieces, writes at most `cap`
+ * entries per array, any array may be NULL): piece k covers rows [firstRow[k], firstRow[k] + rows[k]), belongs to
+ * GPU owner[k] and starts at row rowInOwner[k] of that GPU's own buffer of ownedRows[owner[k]] rows (ownedRows has
+ * nDevices entries); graftFramePieces is the same without the last two.  graftRenderFrameMulti is graftRenderRows for
+ * the whole frame over all bound GPUs, host buffers out; with one GPU bound it IS graftRenderRows.  The scene is packed
+ * once and uploaded to every GPU; traces leave 4 CUs of every GPU to the transfer kernels.  graftMultiStats reports,
+ * for one GPU of the last multi-GPU frame, the time from its first kernel to its last (traceMs) and from its last
+ * kernel to its last transfer (tailMs: the part of the exchange tracing did not hide; negative if none). */
 GRAFT_API int graftInitDevices(int nDevices);
+GRAFT_API int graftFramePlan(int nRows, int nDevices, int piecesPerDevice, int *firstRow, int *rows, int *owner,
+                             int *rowInOwner, int *ownedRows, int cap);
 GRAFT_API int graftFramePieces(int nRows, int nDevices, int piecesPerDevice, int *firstRow, int *rows, int *owner, int cap);
+GRAFT_API int graftMultiStats(int device, float *traceMs, float *tailMs);
 GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *view, int format, int piecesPerDevice,
                                     void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost);
 

@@ -14,7 +14,7 @@ GRAFT_OK, GRAFT_ERR_ARG, GRAFT_ERR_UNSUPPORTED, GRAFT_ERR_HIP, GRAFT_ERR_STATE =
 GRAFT_SPHERE, GRAFT_PLANE = 0, 1
 GRAFT_ORTHOGRAPHIC, GRAFT_PERSPECTIVE = 0, 1
 GRAFT_OUT_F64_RGB, GRAFT_OUT_F32_RGBA, GRAFT_OUT_U8_RGBA = 0, 1, 2
-DIAGNOSTICS = {"screen_cap": 0, "group_size": 1, "tiles_per_ticket": 2, "table_builds": 4}
+DIAGNOSTICS = {"screen_cap": 0, "group_size": 1, "tiles_per_ticket": 2, "table_builds": 4, "reserved_cus": 5}
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
@@ -90,6 +90,10 @@ lib.graftRenderRowsNoAlloc.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTE
                                        ctypes.c_void_p]
 lib.graftInitDevices.argtypes = [ctypes.c_int]
 lib.graftFramePieces.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p, ctypes.c_int]
+if hasattr(lib, "graftFramePlan"):  # (an older build loaded through GRAFT_LIB for A/B timing may lack these two)
+    lib.graftFramePlan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
+                                   c_int32_p, ctypes.c_int]
+    lib.graftMultiStats.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
 lib.graftRenderFrameMulti.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTER(GraftView), ctypes.c_int, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 lib.graftWritePPM.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]

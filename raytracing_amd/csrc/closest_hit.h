@@ -27,6 +27,30 @@ __device__ __forceinline__ void unit3(double vx, double vy, double vz, double &o
     }
 }
 
+// vecUnit again, for the hot stages: the three quotients share the divisor, and so does most of the division the
+// compiler emits for each (scale, reciprocal, two Newton steps on the divisor alone).  With the length and the three
+// components all between 2^-400 and 2^400 nothing is scaled and no special case arises, and the remaining steps per
+// component -- q = x r, e = fma(-m, q, x), q' = fma(e, r, q) -- are the sequence's own: the result is the correctly
+// rounded quotient, bit for bit what `/` gives.  Anything else (a zero component among them) takes `/`.
+__device__ __forceinline__ void unit3Shared(double vx, double vy, double vz, double &ox, double &oy, double &oz) {
+    const double mag = sqrt(dot3(vx, vy, vz, vx, vy, vz));
+    const double lo = 0x1p-400, hi = 0x1p400;
+    const double ax = fabs(vx), ay = fabs(vy), az = fabs(vz);
+    if (mag > lo && mag < hi && fmin(ax, fmin(ay, az)) > lo) {  // (components never exceed the length by more than rounding)
+        double r = __builtin_amdgcn_rcp(mag);
+        r = __builtin_fma(__builtin_fma(-mag, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-mag, r, 1.0), r, r);
+        const double qx = vx * r, qy = vy * r, qz = vz * r;
+        ox = __builtin_fma(__builtin_fma(-mag, qx, vx), r, qx);
+        oy = __builtin_fma(__builtin_fma(-mag, qy, vy), r, qy);
+        oz = __builtin_fma(__builtin_fma(-mag, qz, vz), r, qz);
+    } else if (mag > 0) {
+        ox = vx / mag;
+        oy = vy / mag;
+        oz = vz / mag;
+    }
+}
+
 // mainTracing.c:104-114 with the denominator dir.dir hoisted (it only depends on dir)
 __device__ __forceinline__ void newPoint(const double start[3], const double dir[3], double den, double dist,
                                          double out[3]) {
@@ -186,33 +210,35 @@ __device__ __forceinline__ void exactSphereLazy(const double4v c4, int shape, do
     const double b = vx * dx + vy * dy + vz * dz;
     const double vv = vx * vx + vy * vy + vz * vz;
     const double w = vv - c4.w;
+    const double bb = b * b;
+    const double disc = bb - w;
     // Origin outside the sphere and moving away from its centre: both roots are negative.  disc = fl(b b - w) is
     // at least two units in the last place below fl(b b), so its root is below b and t = -b + q < 0 (shapes.c:62-66).
-    if (b > 0 && w > b * b * 8.9e-16) return;
-    const double disc = b * b - w;
-    if (!(disc < 0)) {
+    // (Few branches on purpose: lanes of a wave disagree on nearly every one of them, and every level of nesting
+    // costs copies of the values that live across it.)
+    double t = -1;
+    if (!(b > 0 && w > bb * 8.9e-16) && !(disc < 0)) {
         const double q = sqrt(disc);
         const double bz = b + 0.0;  // restores the +0 of the reference's dot product
         const double tFar = -bz + q;
         const double tNear = -bz - q;
-        const double t = tNear >= 0 ? tNear : tFar;
-        if (!(t < 0)) {
-            if (best.shape < 0) {
-                best.t = t; best.dist = -1; best.shape = shape;
-            } else {
-                const double slackNew = slackScale * (t + slackBase), slackBest = slackScale * (best.t + slackBase);
-                if (t + slackNew < best.t - slackBest) {
-                    best.t = t; best.dist = -1; best.shape = shape;
-                } else if (!(t - slackNew > best.t + slackBest)) {
-                    if (best.dist < 0) best.dist = hitDistance(best.t, sx, sy, sz, dx, dy, dz);
-                    const double dist = hitDistance(t, sx, sy, sz, dx, dy, dz);
-                    if (dist < best.dist || (dist == best.dist && shape < best.shape)) {
-                        best.t = t; best.dist = dist; best.shape = shape;
-                    }
-                }
-            }
+        t = tNear >= 0 ? tNear : tFar;
+    }
+    const bool hit = !(t < 0);  // (true for NaN, as in the reference: shapes.c:66 only rejects t < 0)
+    const double slackNew = slackScale * (t + slackBase), slackBest = slackScale * (best.t + slackBase);
+    const bool first = best.shape < 0;
+    const bool closer = hit && (first || t + slackNew < best.t - slackBest);
+    const bool tied = hit && !closer && !(t - slackNew > best.t + slackBest);
+    if (tied) {  // rare: too close for the ray parameters to decide; the reference's own comparison of distances
+        if (best.dist < 0) best.dist = hitDistance(best.t, sx, sy, sz, dx, dy, dz);
+        const double dist = hitDistance(t, sx, sy, sz, dx, dy, dz);
+        if (dist < best.dist || (dist == best.dist && shape < best.shape)) {
+            best.t = t; best.dist = dist; best.shape = shape;
         }
     }
+    best.t = closer ? t : best.t;
+    best.dist = closer ? -1.0 : best.dist;
+    best.shape = closer ? shape : best.shape;
 }
 
 __device__ __forceinline__ void exactSphereLazy(const double *geom, int shape, double sx, double sy, double sz, double dx,
@@ -683,8 +709,11 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
     const int nx = P.gridNx, ny = P.gridNy, nz = P.gridNz;
 
     // The part of the ray inside the grid's box, and per axis: step, parameter of the next cell face, parameter per
-    // cell.  Set up in double precision, stepped in single: the walk's idea of the ray parameter is then off by at
-    // most (steps x half an ulp of t) ~ 4e-5 of the coordinate scale, which the grid's margin (packGrid) covers.
+    // cell.  Set up in double precision, stepped in single -- as parameters RELATIVE TO THE ENTRY POINT, which never
+    // exceed the box's diagonal however far away the ray starts (an orthographic view's screen plane may lie tens
+    // of thousands of units from a compact scene): the walk's idea of the ray parameter is then off by at most
+    // (steps x half an ulp of a parameter below 3.5 S) ~ 4e-5 of the spheres' coordinate scale S, which the grid's
+    // margin (packGrid) covers.
     double tEnter = 0, tLeave = INFINITY;
     bool alive = true;
     float tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ;
@@ -715,7 +744,7 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
         if (inv != 0) {
             step = d > 0 ? 1 : -1;
             const double face = lo + (f + (d > 0 ? 1.0 : 0.0)) * cs;
-            tMax = (float)((face - o) * inv);
+            tMax = (float)((face - o) * inv - tEnter);
             tDelta = (float)(cs * fabs(inv));
         } else {
             step = 0;
@@ -729,9 +758,10 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
 
     const bool shadow = tLimit < INFINITY;
     const double tSure = tLimit * (1 - 1e-5) - 1e-5;
-    const float tStop = shadow ? (float)(tLimit * (1 + 1e-5) + 1e-5) : INFINITY;
-    // A lane goes on to the next cell while tExit < goOn: infinity until there is a hit, then the hit's parameter
-    // less a slack that covers single precision (or minus infinity once a shadow ray is known to be blocked).
+    const float tStop = shadow ? (float)(tLimit * (1 + 1e-5) + 1e-5 - tEnter) : INFINITY;
+    // A lane goes on to the next cell while tExit < goOn (both relative to the entry point): infinity until there is
+    // a hit, then the hit's parameter less a slack that covers single precision (or minus infinity once a shadow ray
+    // is known to be blocked).
     float goOn = tStop;
     // the lane's cell: entries not yet looked at, the next two of them, and where the ones after those are listed
     int left = 0, kA = 0, kB = 0, ref = 0;
@@ -801,7 +831,7 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
                         exactSphereLazy(pendingGeom, pending, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
                         pending = -1;
                         if (closest.shape >= 0) {
-                            const float guard = (float)(closest.t - (1e-5 * (fabs(closest.t) + slackBase) + 1e-6));
+                            const float guard = (float)(closest.t - tEnter - (1e-5 * (fabs(closest.t) + slackBase) + 1e-6));
                             goOn = shadow && closest.t < tSure ? -INFINITY : fminf(tStop, guard);
                         }
                     }
@@ -854,24 +884,22 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
 // no list of a ray has a provably negative discriminant in the reference (or can only be met beyond the light, which
 // lighting() treats like no hit, mainTracing.c:211-215), so hit masks, hit points and colours are unchanged.
 
-// The cone that bounds every primary ray of a tile, as (axis, cos, sin of the half-angle), and whether an entry
-// (a, -kappa2) of a cone table can be met by a line inside it.  The table's kappa2 = cos^2(A) - 16 u rounded down
+// The cone that bounds every primary ray of a tile, as (axis t, cos, sin of the half-angle tau), and whether an entry
+// (a, kappa2) of a cone table can be met by a line inside it.  The table's kappa2 = cos^2(A) - 16 u rounded down
 // (packConeTable; u = 2^-24) stands for an angle A' >= A with cos A' <= cos A - 4.8e-7; the entry is left out iff
-// |a . t| + 1e-9 < cos(A' + tau): then the angle between the axis t and the entry's axis (as lines) exceeds
-// A + tau even after the entry's axis was rounded to float (|a . t| is off by at most 1.2e-7), and every line within
-// tau of t misses the entry's cone.  Evaluated in double precision; once per tile and lane, so cost does not matter.
+// |a . t| + 1e-9 < cos(A' + tau) = cos A' cos tau - sin A' sin tau: then the angle between the axis t and the entry's
+// axis (as lines) exceeds A + tau even after the entry's axis was rounded to float (|a . t| is off by at most 1.2e-7),
+// and every line within tau of t misses the entry's cone.  Evaluated in double precision.
 struct TileCone {
     double ax, ay, az, cosT, sinT;
     bool ok;  // false: no usable bound (non-finite or wide): the tile lists every sphere
 };
 
-__device__ __forceinline__ bool coneMeetsTile(const float4v e, const TileCone &T) {
-    if (e.w >= 0.0f) return true;                     // kappa2 = -1: always passes
-    const double k2 = -(double)e.w;
-    if (!(k2 <= 1.0)) return false;                   // -inf: never passes (padding)
-    const double cosA = sqrt(k2), sinA = sqrt(1.0 - k2);
-    const double c = fabs((double)e.x * T.ax + (double)e.y * T.ay + (double)e.z * T.az);
-    return c + 1e-9 >= cosA * T.cosT - sinA * T.sinT;
+// entry = {axis, cos A'} with the sine in a table of its own (packLevel6 forms both from the cone table's kappa2, the
+// cosine rounded down and the sine up); cos A' = -2 always passes, +inf never does
+__device__ __forceinline__ bool coneMeetsTile(const float4v e, float sinA, const TileCone &T) {
+    const double c = fabs(__builtin_fma((double)e.z, T.az, __builtin_fma((double)e.y, T.ay, (double)e.x * T.ax)));
+    return c + 1e-9 >= __builtin_fma(-(double)sinA, T.sinT, (double)e.w * T.cosT);
 }
 
 // The wave's tile list: sphere numbers (16 bits) at `list` in LDS; returns the count, or -1 when the list would
@@ -906,14 +934,17 @@ __device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles 
     T.ok = tt > 0 && tt < 1e300 && sinT < 0.5;  // (false for NaN)
     if (!T.ok) return -1;
 
+    // (group entries first, member entries behind them, in both tables)
     const float4v *groups = (const float4v *)((const char *)ldsGeom + P.listGroupsOff);
-    const float4v *members = (const float4v *)((const char *)ldsGeom + P.listMembersOff);
+    const float4v *members = groups + P.listGroups;
+    const float *groupSin = (const float *)((const char *)ldsGeom + P.listSinesOff), *memberSin = groupSin + P.listGroups;
     const unsigned short *shapeOf = (const unsigned short *)((const char *)ldsGeom + P.listShapeOff);
     const int gs = P.groupSize;
     int count = 0;
     for (int g0 = 0; g0 < P.listGroups; g0 += 64) {
         const int g = g0 + lane;
-        unsigned long long open = __ballot(g < P.listGroups && coneMeetsTile(groups[g < P.listGroups ? g : 0], T));
+        const int gRead = g < P.listGroups ? g : 0;
+        unsigned long long open = __ballot(g < P.listGroups && coneMeetsTile(groups[gRead], groupSin[gRead], T));
         while (open) {
             const int gOpen = g0 + (int)__builtin_ctzll(open);
             open &= open - 1;
@@ -922,7 +953,7 @@ __device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles 
             unsigned short id = 0xffff;
             if (lane < gs) {
                 id = shapeOf[gOpen * gs + lane];
-                take = id != 0xffff && coneMeetsTile(members[gOpen * gs + lane], T);
+                take = id != 0xffff && coneMeetsTile(members[gOpen * gs + lane], memberSin[gOpen * gs + lane], T);
             }
             const unsigned long long taken = __ballot(take);
             const int at = count + (int)__popcll(taken & ((1ull << lane) - 1));
@@ -937,8 +968,11 @@ __device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles 
 // parked per lane and the exact test runs, for every lane that has one parked, when some lane needs the slot again
 // or has reached the end of its list -- one code site, shared by lanes whose lists differ.  Spheres are met out of
 // index order: see closestHitGrouped for why the winner does not depend on it.
+// `self` >= 0: the sphere a shadow ray starts on, which its list leaves out.  The ray starts a hair outside it; when
+// it moves away from the centre (the light lies in front of the surface) both roots are negative and the sphere is
+// done with (the first clause of exactSphereLazy: shapes.c:62-66 reports a miss); otherwise it is the first candidate.
 __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx, double sy, double sz, double dx, double dy,
-                                                double dz, int pos, int len, float negThreshold, Hit &h) {
+                                                double dz, int pos, int len, int self, float negThreshold, Hit &h) {
     const float4v *aos = (const float4v *)ldsGeom;
     const double4v *geom = (const double4v *)((const char *)ldsGeom + P.exactLdsOffset);
     const unsigned short *pool = (const unsigned short *)((const char *)ldsGeom + P.listPoolOff);
@@ -950,6 +984,13 @@ __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx,
     const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
     int pending = -1;
     double4v pendingGeom = {0, 0, 0, 0};
+    if (self >= 0) {
+        pendingGeom = geom[self];
+        const double vx = sx - pendingGeom.x, vy = sy - pendingGeom.y, vz = sz - pendingGeom.z;
+        const double b = vx * dx + vy * dy + vz * dz;
+        const double w = (vx * vx + vy * vy + vz * vz) - pendingGeom.w;
+        if (!(b > 0 && w > b * b * 8.9e-16)) pending = self;
+    }
     while (__ballot(len > 0 || pending >= 0)) {
         int j = -1;
         if (len > 0) {

@@ -34,6 +34,13 @@
 
 using namespace graft;
 
+#ifndef GRAFT_SAMPLE_TABLE
+#define GRAFT_SAMPLE_TABLE 1
+#endif
+#ifndef GRAFT_SHARED_RCP
+#define GRAFT_SHARED_RCP 1
+#endif
+
 // Device memory of the entry point that allocates nothing (graftRenderRowsNoAlloc): every GPU the library runs on
 // holds one copy of this array, at an address of its own, until the process ends.  Host code never uses the name
 // as an address: graftInit asks the runtime for the array's device address (hipGetSymbolAddress, with that device
@@ -82,9 +89,13 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     const int lane = threadIdx.x & 63;
     const int lx = lane & (kTile - 1), ly = lane >> 3;
     const int nSamples = P.aliasing ? P.numPasses * P.numPasses : 1;
-    // rayCount, testCount: the closest-hit queries and ray-shape evaluations of the reference for these pixels;
-    // tracedCount: the queries made here (shadow rays whose answer cannot matter are not shot, see the lights' loop)
-    unsigned long long rayCount = 0, testCount = 0, tracedCount = 0;
+    // Ray statistics (GraftCounters): the reference's closest-hit queries and ray-shape evaluations for these pixels,
+    // and the queries answered here (shadow rays whose answer cannot matter are not shot, see the lights' loop).  Per
+    // lane and tile three small counts -- queries other than shadow rays (the reference makes exactly those too), shaded
+    // hits (the reference shoots numLights shadow rays for each), queries answered; they are summed over the wave at
+    // the end of a tile, and only in launches that asked for counters.
+    unsigned long long rayCount = 0, testCount = 0, tracedCount = 0;  // wave totals (uniform)
+    unsigned nOther = 0, nHits = 0, nAnswered = 0;
 #ifdef GRAFT_STAMPS  // diagnostic build only: shader-clock cycles per wave in the closest-hit call and in total
     unsigned long long stampHit = 0, stampRounds = 0, stampLoop = 0;
     const unsigned long long stampBegin = clock64();
@@ -109,20 +120,26 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         }
         if (SCREEN) {
             const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
-            const bool tame = s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001;
+            // (level 6: every direction comes out of vecUnit -- unit length or the zero vector -- and every origin is a
+            // screen point or a point of a sphere, all finite in a job that qualifies; the test on the origin stays)
+            const bool tame = SCREEN == 6 || (s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001);
             if (tame && (SCREEN == 1 || s1 < (SCREEN >= 3 ? P.familyScale : 1e5))) {
                 const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
                 if (SCREEN == 6) {
                     // the lane's list: the occluders of (sphere the ray starts on, light), or what the tile can see
-                    int pos = tileListPos, len = tileListLen;
+                    // (a shadow ray's own sphere is not on its list: closestHitLists looks at it first)
+                    int pos = tileListPos, len = tileListLen, self = -1;
                     if (mode == M_SHADOW) {
                         const unsigned *index = (const unsigned *)((const char *)ldsGeom + P.listIndexOff);
                         const unsigned w = index[from * P.numLights + li];
                         pos = (int)(w & 0xfffffu);
                         len = (int)(w >> 20);
+                        self = from;
+                        if (AVOID == 1 && from == avoidShape) self = -1;
+                        if (AVOID == 2 && avoidRow && avoidRow[from]) self = -1;
                     }
-                    if (len == (int)kListAll) { pos = 0; len = P.numSpheres; }  // (the pool starts with every sphere)
-                    closestHitLists(P, o[0], o[1], o[2], d[0], d[1], d[2], pos, len, negThreshold, h);
+                    if (len == (int)kListAll) { pos = 0; len = P.numSpheres; self = -1; }  // (the pool starts with every sphere)
+                    closestHitLists(P, o[0], o[1], o[2], d[0], d[1], d[2], pos, len, self, negThreshold, h);
                 } else if (SCREEN >= 3) {
                     // which fixed point the ray's line passes through decides the table it is screened with
                     int family = P.ballFamily;
@@ -212,6 +229,20 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                                             P.rowOff[iy0] + fmin(spanY, 0.0), P.rowOff[iy1] + fmax(spanY, 0.0),
                                             (unsigned short *)((char *)ldsGeom + P.listTileOff) + (threadIdx.x >> 6) * kTileListCap);
             tileListLen = found < 0 ? (int)kListAll : found;
+            // Supersampling: the scale factor of a sample's first getNewPoint step (mainTracing.c:405, :107-108: a
+            // division and a square root) depends on (column, k) only, that of the second (:406) on (row, l): all
+            // 16 numPasses of them are worked out once per tile, one per lane, and read back per sample.
+            if (GRAFT_SAMPLE_TABLE && !MANYCURSORS && P.sampleTableOff >= 0) {
+                double *tab = (double *)((char *)ldsGeom + P.sampleTableOff) + (threadIdx.x >> 6) * 16 * P.numPasses;
+                if (lane < kTile * P.numPasses) {
+                    const int c = (int)__umulhi((unsigned)lane, P.numPassesRecip), k = lane - c * P.numPasses;
+                    const double offX = P.colOff[min(ix0 + c, ix1)] + cam[CAM_SUBX] * (double)(k + 1);
+                    const double offY = P.rowOff[min(iy0 + c, iy1)] + cam[CAM_SUBY] * (double)(k + 1);
+                    const double scaleX = sqrt(offX * offX / cam[CAM_LRDEN]), scaleY = sqrt(offY * offY / cam[CAM_UDDEN]);
+                    tab[lane] = offX < 0 ? -scaleX : scaleX;
+                    tab[kTile * P.numPasses + lane] = offY < 0 ? -scaleY : scaleY;
+                }
+            }
         }
         double acc[3] = {cam[CAM_BACKGROUND], cam[CAM_BACKGROUND + 1], cam[CAM_BACKGROUND + 2]};  // mainTracing.c:395
         int firstIdx = -1;
@@ -232,14 +263,31 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             int rayReflects = 1;               // shouldReflect of the ray being traced (mainTracing.c:300)
             double tLimit = INFINITY;          // shadow rays: ray parameter of the light (see closestHitGrid)
 
-            auto startSample = [&](int s) {
+            // the screen point of sample s (k = s / numPasses outer, l inner: mainTracing.c:401-408)
+            auto samplePoint = [&](int s, double out[3]) {
                 double xo = colI, yo = rowJ;
-                if (P.aliasing) {  // mainTracing.c:401-406: k outer, l inner
-                    const int k = s / P.numPasses, l = s - k * P.numPasses;
+                if (P.aliasing) {
+                    // k = s / numPasses by a multiplication (exact below 2^20 samples, host_job.h)
+                    const int k = (int)__umulhi((unsigned)s, P.numPassesRecip), l = s - k * P.numPasses;
+                    if (SCREEN == 6 && GRAFT_SAMPLE_TABLE && !MANYCURSORS && P.sampleTableOff >= 0) {  // the two steps' scale factors from the tile's table
+                        const double *tab = (const double *)((const char *)ldsGeom + P.sampleTableOff) + (threadIdx.x >> 6) * 16 * P.numPasses;
+                        const double scaleX = tab[lx * P.numPasses + k], scaleY = tab[(kTile + ly) * P.numPasses + l];
+                        for (int c = 0; c < 3; ++c) {
+                            const double col = cam[CAM_SCREEN + c] + scaleX * cam[CAM_LR + c];
+                            out[c] = col + scaleY * cam[CAM_UD + c];
+                        }
+                        return;
+                    }
                     xo = colI + cam[CAM_SUBX] * (double)(k + 1);
                     yo = rowJ + cam[CAM_SUBY] * (double)(l + 1);
                 }
-                primaryRay(P, xo, yo, o, d);
+                screenPoint(cam, xo, yo, out);
+            };
+            auto startSample = [&](int s) {
+                samplePoint(s, o);
+                d[0] = d[1] = d[2] = 0;
+                if (P.projectionType == GRAFT_ORTHOGRAPHIC) unit3(-cam[CAM_VIEW], -cam[CAM_VIEW + 1], -cam[CAM_VIEW + 2], d[0], d[1], d[2]);
+                else unit3(o[0] - cam[CAM_POS], o[1] - cam[CAM_POS + 1], o[2] - cam[CAM_POS + 2], d[0], d[1], d[2]);
                 depth = 0;
                 sp = 0;
                 rayReflects = 1;  // launchRays passes shouldReflect = 1, mainTracing.c:391
@@ -275,7 +323,19 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             // maxDepth <= 0: shootRay returns black before it looks at the scene (mainTracing.c:302-306), for every
             // sample; with anti-aliasing the background-seeded sum (:395) takes n additions of zero
             const bool traceNothing = P.maxDepth <= 0;
-            if (P.hitIndex && (P.aliasing || traceNothing)) {  // mask ray = the anti-aliasing-off ray of this pixel
+            if (SCREEN == 6 && tileListLen == 0 && !traceNothing) {
+                // No sphere can be met by any primary ray of this tile (mask ray included): every sample is the
+                // background colour (mainTracing.c:314-317), summed as the reference sums it (:419).  The queries
+                // count as answered.
+                const unsigned queries = (unsigned)nSamples + (P.hitIndex && P.aliasing ? 1u : 0u);
+                nOther += queries;
+                nAnswered += queries;
+                if (P.aliasing)
+                    for (int s = 0; s < nSamples; ++s) {
+                        acc[0] = acc[0] + cam[CAM_BACKGROUND]; acc[1] = acc[1] + cam[CAM_BACKGROUND + 1]; acc[2] = acc[2] + cam[CAM_BACKGROUND + 2];
+                    }
+                mode = M_DONE;
+            } else if (P.hitIndex && (P.aliasing || traceNothing)) {  // mask ray = the anti-aliasing-off ray of this pixel
                 primaryRay(P, colI, rowJ, o, d);
                 mode = M_INDEX;
             } else if (traceNothing) {
@@ -298,11 +358,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
 #endif
                 Hit h;
                 const unsigned avoided = closest(o, d, mode, li, depth, hitIdx, mode == M_SHADOW ? tLimit : INFINITY, h);
-                tracedCount++;
-                if (mode != M_SHADOW) {  // (a hit's shadow rays are booked when it is found)
-                    rayCount++;
-                    testCount += (unsigned)P.numShapes;
-                }
+                nAnswered++;
+                if (mode != M_SHADOW) nOther++;  // (a hit's shadow rays are booked when it is found)
                 (void)avoided;
 #ifdef GRAFT_STAMPS
                 const unsigned long long stamp1 = clock64();
@@ -344,7 +401,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                                           : (EXACTLDS || SCREEN == 6) ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
                         if (h.kind == GRAFT_SPHERE) {  // shapes.c:69-71
                             const double *c = g + 4 * (size_t)h.slot;
-                            unit3(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
+                            if (SCREEN == 6 && GRAFT_SHARED_RCP) unit3Shared(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
+                            else unit3(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
                         } else {  // shapes.c:91
                             const double *pn = g + 4 * (size_t)P.numSpheres + 6 * (size_t)h.slot + 3;
                             nrm[0] = pn[0]; nrm[1] = pn[1]; nrm[2] = pn[2];
@@ -355,8 +413,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         // unshadowed light OVERWRITES rgb (:223-225): its result is the last unshadowed light's.  So
                         // the lights are gone through last to first and the first one found unshadowed ends the loop:
                         // what the lights before it would have answered is never looked at by the reference either.
-                        rayCount += (unsigned)P.numLights;
-                        testCount += (unsigned long long)P.numLights * (unsigned)P.numShapes - (unsigned)P.avoidTotal;
+                        nHits++;
                         // A light behind the surface (cosine with the normal below zero) adds nothing whether it is
                         // shadowed or not (diffInt < 0 ? 0, :219); its shadow ray only decides whether the lights
                         // BEFORE it are overwritten.  Once every light still to be asked lies behind the surface
@@ -548,14 +605,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     } else if (next == NEXT_MIRROR) {  // reflection(), mainTracing.c:180-190
                         vx = d[0]; vy = d[1]; vz = d[2];
                     } else {  // the sample's primary ray, mainTracing.c:401-417 / :425-437
-                        double xo = colI, yo = rowJ;
-                        if (P.aliasing) {  // k outer, l inner
-                            // k = sample / numPasses by a multiplication (exact below 2^20 samples, host_job.h)
-                            const int k = (int)__umulhi((unsigned)sample, P.numPassesRecip), l = sample - k * P.numPasses;
-                            xo = colI + cam[CAM_SUBX] * (double)(k + 1);
-                            yo = rowJ + cam[CAM_SUBY] * (double)(l + 1);
-                        }
-                        screenPoint(cam, xo, yo, o);
+                        samplePoint(sample, o);
                         if (P.projectionType == GRAFT_ORTHOGRAPHIC) {
                             vx = -cam[CAM_VIEW]; vy = -cam[CAM_VIEW + 1]; vz = -cam[CAM_VIEW + 2];
                         } else {
@@ -567,7 +617,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         rayReflects = 1;  // launchRays passes shouldReflect = 1, mainTracing.c:391
                         mode = M_RADIANCE;
                     }
-                    unit3(vx, vy, vz, d[0], d[1], d[2]);
+                    if (SCREEN == 6 && GRAFT_SHARED_RCP) unit3Shared(vx, vy, vz, d[0], d[1], d[2]);
+                    else unit3(vx, vy, vz, d[0], d[1], d[2]);
                     if (next != NEXT_SAMPLE) {  // vecNudge, mainTracing.c:163-167
                         o[0] = loc[0] + .000001 * d[0];
                         o[1] = loc[1] + .000001 * d[1];
@@ -590,13 +641,25 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             if (P.hitIndex) P.hitIndex[pixel] = firstIdx;
             storeColor(pixel, acc);
         }
+        if (P.counters) {  // (all lanes: the shuffles read lanes outside the frame too, whose counts are zero)
+            unsigned long long other = nOther, hits = nHits, answered = nAnswered;
+            for (int off = 32; off > 0; off >>= 1) {
+                other += __shfl_down(other, off);
+                hits += __shfl_down(hits, off);
+                answered += __shfl_down(answered, off);
+            }
+            other = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(other >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)other);
+            hits = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(hits >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)hits);
+            answered = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(answered >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)answered);
+            rayCount += other + hits * (unsigned)P.numLights;
+            testCount += other * (unsigned)P.numShapes + hits * ((unsigned long long)P.numLights * (unsigned)P.numShapes - (unsigned)P.avoidTotal);
+            tracedCount += answered;
+        }
+        nOther = nHits = nAnswered = 0;
         ++tile;
     }
     if (P.counters) {
         for (int off = 32; off > 0; off >>= 1) {
-            rayCount += __shfl_down(rayCount, off);
-            testCount += __shfl_down(testCount, off);
-            tracedCount += __shfl_down(tracedCount, off);
 #ifdef GRAFT_STAMPS
             stampHit += __shfl_down(stampHit, off);
             stampRounds += __shfl_down(stampRounds, off);
@@ -670,6 +733,7 @@ struct Reusable {
 };
 
 constexpr int kMaxDevices = 16;
+constexpr int kMultiReservedCUs = 4;  // CUs a multi-device frame's traces leave to the transfer kernels
 constexpr size_t kScratchBytes = (size_t)4 << 20;  // device block of graftRenderRowsNoAlloc: tables + ticket counters
 
 // What the library holds per GPU.
@@ -682,6 +746,8 @@ struct Device {
     std::vector<unsigned char> cacheKey;  // the input that job was packed from
     GraftJob *cacheJob = nullptr;
     std::vector<const void *> configured;  // kernels whose dynamic-LDS limit has been raised on this device
+    struct Occupancy { const void *fn; int block; size_t ldsBytes; int perCU; };
+    std::vector<Occupancy> occupancy;      // resident workgroups per CU, as the runtime answered
     // graftRenderRowsNoAlloc: this device's copy of `scratch`, a page-locked staging block of the same size and the
     // event that says the last upload from it has finished (all three set up by graftInit, never per call)
     unsigned char *scratch = nullptr;
@@ -691,6 +757,7 @@ struct Device {
     // orders it behind `stream`, this device's rank in the communicator and its pieces' buffers
     hipStream_t moveStream = nullptr;
     hipEvent_t traced = nullptr;
+    hipEvent_t frameStart = nullptr, kernelsDone = nullptr, movesDone = nullptr;  // timed: a frame's first kernel queued, its last kernel and its last transfer done
     ncclComm_t comm = nullptr;
     Reusable pieces, pieceIndex;
 };
@@ -708,6 +775,9 @@ struct Rccl {
 };
 Rccl gRccl;
 int gMultiDevices = 0;  // devices 0 .. gMultiDevices-1 bound by graftInitDevices
+// what the last multi-device frame measured per device (graftMultiStats)
+float gMultiTraceMs[kMaxDevices], gMultiTailMs[kMaxDevices];
+int gMultiStatsDevices = 0;
 
 Device gDevices[kMaxDevices];
 Device *gBound = nullptr;  // the device of graftInit: the single-device entry points work on it
@@ -724,6 +794,7 @@ void readSettingsOnce() {
         if (e[0] >= '0' && e[0] <= '0' + kMaxScreen && !e[1]) gSettings.screenCap = e[0] - '0';
     if (const char *e = getenv("GRAFT_GROUP")) gSettings.groupSize = atoi(e);
     if (const char *e = getenv("GRAFT_PER_TICKET")) gSettings.tilesPerTicket = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char *e = getenv("GRAFT_RESERVED_CUS")) gSettings.reservedCUs = atoi(e) > 0 ? atoi(e) : 0;
 }
 
 typedef void (*TraceFn)(const TraceParams);
@@ -783,8 +854,6 @@ struct GraftJob {
     bool mirrors;   // some shape reflects
     size_t ldsBytes;
     int block;
-    int blocksPerCU;  // resident workgroups per CU of kernel `occupancyOf` (asked when a trace first uses a kernel)
-    const void *occupancyOf;
     void *arena;      // the device block holding every table
     bool ownsArena;   // false: the block belongs to a Device (graftRenderRows' cached job)
     Device *dev;
@@ -802,12 +871,12 @@ void describe(GraftJob *job, const PackedJob &J, void *base, bool owns, Device *
     job->mirrors = J.mirrors;
     job->ldsBytes = J.ldsBytes;
     job->block = J.block;
-    job->blocksPerCU = 0;
-    job->occupancyOf = nullptr;
     job->arena = base;
     job->ownsArena = owns;
     job->dev = dev;
 }
+
+void releaseDevice(Device &D);
 
 int initDevice(int device, Device **out) {
     int n = 0;
@@ -816,16 +885,25 @@ int initDevice(int device, Device **out) {
     Device &D = gDevices[device];
     if (!D.ready) {
         readSettingsOnce();
-        HIP_TRY(hipSetDevice(device));
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        D.numCU = prop.multiProcessorCount;
-        HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
-        static_assert(sizeof(scratch) == kScratchBytes, "scratch size");
-        HIP_TRY(hipGetSymbolAddress((void **)&D.scratch, HIP_SYMBOL(scratch)));  // this device's copy of the array
-        HIP_TRY(hipHostMalloc((void **)&D.scratchStage, kScratchBytes, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&D.scratchCopied, hipEventDisableTiming));
         D.id = device;
+        auto create = [&]() -> int {
+            HIP_TRY(hipSetDevice(device));
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, device));
+            D.numCU = prop.multiProcessorCount;
+            HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+            static_assert(sizeof(scratch) == kScratchBytes, "scratch size");
+            HIP_TRY(hipGetSymbolAddress((void **)&D.scratch, HIP_SYMBOL(scratch)));  // this device's copy of the array
+            HIP_TRY(hipHostMalloc((void **)&D.scratchStage, kScratchBytes, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&D.scratchCopied, hipEventDisableTiming));
+            return GRAFT_OK;
+        };
+        const int rc = create();
+        if (rc != GRAFT_OK) {  // nothing half-made stays behind: the next call starts from scratch
+            D.ready = true;
+            releaseDevice(D);
+            return rc;
+        }
         D.ready = true;
     }
     *out = &D;
@@ -843,8 +921,12 @@ void releaseDevice(Device &D) {
     D.comm = nullptr;
     if (D.moveStream) (void)hipStreamDestroy(D.moveStream);
     if (D.traced) (void)hipEventDestroy(D.traced);
+    if (D.frameStart) (void)hipEventDestroy(D.frameStart);
+    if (D.kernelsDone) (void)hipEventDestroy(D.kernelsDone);
+    if (D.movesDone) (void)hipEventDestroy(D.movesDone);
     D.moveStream = nullptr;
     D.traced = nullptr;
+    D.frameStart = D.kernelsDone = D.movesDone = nullptr;
     D.pieces.release();
     D.pieceIndex.release();
     if (D.scratchCopied) (void)hipEventDestroy(D.scratchCopied);
@@ -860,6 +942,7 @@ void releaseDevice(Device &D) {
     D.counters.release();
     D.arena.release();
     D.configured.clear();
+    D.occupancy.clear();
     D.stream = nullptr;
     D.ready = false;
 }
@@ -886,15 +969,23 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
         HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
         D->configured.push_back((const void *)fn);
     }
-    if (job->occupancyOf != (const void *)fn) {  // persistent grid: as many workgroups as the kernel's registers and LDS let a CU hold
+    // persistent grid: as many workgroups as the kernel's registers and LDS let a CU hold (asked once per device, kernel,
+    // workgroup size and LDS footprint)
+    int blocksPerCU = 0;
+    for (const Device::Occupancy &o : D->occupancy)
+        if (o.fn == (const void *)fn && o.block == job->block && o.ldsBytes == job->ldsBytes) blocksPerCU = o.perCU;
+    if (!blocksPerCU) {
         int perCU = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)fn, job->block, job->ldsBytes));
-        job->blocksPerCU = perCU < 1 ? 1 : perCU;
-        job->occupancyOf = (const void *)fn;
+        blocksPerCU = perCU < 1 ? 1 : perCU;
+        if (D->occupancy.size() >= 64) D->occupancy.clear();
+        D->occupancy.push_back({(const void *)fn, job->block, job->ldsBytes, blocksPerCU});
     }
-    const int blocksPerCU = job->blocksPerCU;
     long long wantBlocks = (tiles + wavesPerBlock - 1) / wavesPerBlock;
-    long long maxBlocks = (long long)D->numCU * blocksPerCU;
+    // (reserved CUs: a trace that shares its GPU with transfer kernels -- RCCL's send and receive are kernels -- leaves
+    // them room to start at once instead of when one of its own persistent workgroups retires)
+    const int reserved = gSettings.reservedCUs > 0 ? gSettings.reservedCUs : 0;
+    long long maxBlocks = (long long)(D->numCU - reserved > 1 ? D->numCU - reserved : 1) * blocksPerCU;
     const int grid = (int)(wantBlocks < maxBlocks ? wantBlocks : maxBlocks);
     const long long waves = (long long)grid * wavesPerBlock;
     // tiles per ticket: 1 for expensive tiles, 2 for cheap ones, but never so many that a wave gets fewer than 8 draws
@@ -947,6 +1038,7 @@ GRAFT_API void graftShutdown(void) {
     for (Device &D : gDevices) releaseDevice(D);
     gBound = nullptr;
     gMultiDevices = 0;
+    gMultiStatsDevices = 0;
 }
 
 GRAFT_API const char *graftLastError(void) { return gError; }
@@ -966,6 +1058,10 @@ GRAFT_API int graftDiagnosticSet(int which, int value) {
             if (value < 0) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: tiles per ticket %d", value);
             gSettings.tilesPerTicket = value;
             return GRAFT_OK;
+        case GRAFT_DIAG_RESERVED_CUS:
+            if (value < 0 || value > 128) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: %d reserved CUs", value);
+            gSettings.reservedCUs = value;
+            return GRAFT_OK;
         default:
             return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: unknown setting %d", which);
     }
@@ -977,6 +1073,7 @@ GRAFT_API int graftDiagnosticGet(int which) {
         case GRAFT_DIAG_SCREEN_CAP: return gSettings.screenCap;
         case GRAFT_DIAG_GROUP_SIZE: return gSettings.groupSize;
         case GRAFT_DIAG_TILES_PER_TICKET: return gSettings.tilesPerTicket;
+        case GRAFT_DIAG_RESERVED_CUS: return gSettings.reservedCUs;
         case GRAFT_DIAG_TABLE_BUILDS: return (int)(gTables.builds & 0x7fffffff);
         default: return -1;
     }
@@ -1205,26 +1302,39 @@ GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *v
 
 // ---- several GPUs driven by one process ----
 
-GRAFT_API int graftFramePieces(int nRows, int nDevices, int piecesPerDevice, int *firstRow, int *rows, int *owner, int cap) {
+GRAFT_API int graftFramePlan(int nRows, int nDevices, int piecesPerDevice, int *firstRow, int *rows, int *owner,
+                             int *rowInOwner, int *ownedRows, int cap) {
     if (nRows <= 0 || nDevices <= 0) return -1;
     const int tiles = (nRows + kTile - 1) / kTile;
     int count = nDevices * (piecesPerDevice > 1 ? piecesPerDevice : 1);
     if (count > tiles) count = tiles;
     if (count < 1) count = 1;
+    if (ownedRows)
+        for (int d = 0; d < nDevices; ++d) ownedRows[d] = 0;
+    std::vector<int> owned((size_t)nDevices, 0);
     int out = 0;
     for (int k = 0; k < count; ++k) {
         const int r0 = (int)((long long)k * tiles / count) * kTile;
         int r1 = (int)((long long)(k + 1) * tiles / count) * kTile;
         if (r1 > nRows) r1 = nRows;
         if (r1 <= r0) continue;
+        const int who = k % nDevices;
         if (out < cap) {
             if (firstRow) firstRow[out] = r0;
             if (rows) rows[out] = r1 - r0;
-            if (owner) owner[out] = k % nDevices;
+            if (owner) owner[out] = who;
+            if (rowInOwner) rowInOwner[out] = owned[who];
         }
+        owned[who] += r1 - r0;
         ++out;
     }
+    if (ownedRows)
+        for (int d = 0; d < nDevices; ++d) ownedRows[d] = owned[d];
     return out;
+}
+
+GRAFT_API int graftFramePieces(int nRows, int nDevices, int piecesPerDevice, int *firstRow, int *rows, int *owner, int cap) {
+    return graftFramePlan(nRows, nDevices, piecesPerDevice, firstRow, rows, owner, nullptr, nullptr, cap);
 }
 
 GRAFT_API int graftInitDevices(int nDevices) {
@@ -1234,6 +1344,10 @@ GRAFT_API int graftInitDevices(int nDevices) {
         return fail(GRAFT_ERR_ARG, "graftInitDevices: %d devices asked for, %d present (at most %d)", nDevices, n, kMaxDevices);
     if (gBound && gBound->id != 0) return fail(GRAFT_ERR_STATE, "graftInitDevices: already bound to device %d (device 0 is the root)", gBound->id);
     if (gMultiDevices >= nDevices) return GRAFT_OK;
+    // Until every step below has succeeded no multi-device frame can be started: a failure leaves the library with
+    // device 0 only (gMultiDevices = 0: graftRenderFrameMulti refuses), never with half a set of communicators.
+    const int before = gMultiDevices;
+    gMultiDevices = 0;
     for (int d = 0; d < nDevices; ++d) {
         Device *D = nullptr;
         const int rc = initDevice(d, &D);
@@ -1241,6 +1355,9 @@ GRAFT_API int graftInitDevices(int nDevices) {
         HIP_TRY(hipSetDevice(d));
         if (!D->moveStream) HIP_TRY(hipStreamCreateWithFlags(&D->moveStream, hipStreamNonBlocking));
         if (!D->traced) HIP_TRY(hipEventCreateWithFlags(&D->traced, hipEventDisableTiming));
+        if (!D->frameStart) HIP_TRY(hipEventCreate(&D->frameStart));
+        if (!D->kernelsDone) HIP_TRY(hipEventCreate(&D->kernelsDone));
+        if (!D->movesDone) HIP_TRY(hipEventCreate(&D->movesDone));
     }
     if (nDevices > 1) {
         if (!gRccl.handle) {
@@ -1261,18 +1378,57 @@ GRAFT_API int graftInitDevices(int nDevices) {
             }
             gRccl.handle = h;
         }
-        for (int d = 0; d < gMultiDevices; ++d)  // a smaller communicator from an earlier call
+        for (int d = 0; d < before; ++d)  // a smaller communicator from an earlier call
             if (gDevices[d].comm) { (void)gRccl.commDestroy(gDevices[d].comm); gDevices[d].comm = nullptr; }
         ncclComm_t comms[kMaxDevices];
         int ids[kMaxDevices];
         for (int d = 0; d < nDevices; ++d) ids[d] = d;
         const ncclResult_t r = gRccl.commInitAll(comms, nDevices, ids);
-        if (r != ncclSuccess) return fail(GRAFT_ERR_HIP, "ncclCommInitAll(%d): %s", nDevices, gRccl.errorString(r));
+        if (r != ncclSuccess) {
+            (void)hipSetDevice(0);
+            return fail(GRAFT_ERR_HIP, "ncclCommInitAll(%d): %s", nDevices, gRccl.errorString(r));
+        }
         for (int d = 0; d < nDevices; ++d) gDevices[d].comm = comms[d];
     }
     HIP_TRY(hipSetDevice(0));
     gBound = &gDevices[0];
     gMultiDevices = nDevices;
+    return GRAFT_OK;
+}
+
+// The job every one of devices 0 .. G-1 traces: packed ONCE on the host; a device whose cached job was packed from
+// the same input keeps it, the others receive the image.
+static int cachedJobs(int G, const GraftScene *scene, const GraftView *view, GraftJob **jobs) {
+    if (!scene || !view) return fail(GRAFT_ERR_ARG, "graftRenderFrameMulti: null scene or view");
+    if (view->nCols <= 0 || view->nRows <= 0 || !view->colOffsets || !view->rowOffsets)
+        return fail(GRAFT_ERR_ARG, "graftRenderFrameMulti: bad frame %d x %d", view->nCols, view->nRows);
+    std::vector<unsigned char> key;
+    jobKey(scene, view, gSettings, key);
+    PackedJob J;
+    bool packed = false;
+    for (int d = 0; d < G; ++d) {
+        Device *D = &gDevices[d];
+        if (D->cacheJob && key == D->cacheKey) {
+            jobs[d] = D->cacheJob;
+            continue;
+        }
+        if (!packed) {
+            std::string err;
+            const int rc = packJob(scene, view, gSettings, gTables, J, err);
+            if (rc != GRAFT_OK) return fail(rc, "graftRenderFrameMulti: %s", err.c_str());
+            packed = true;
+        }
+        HIP_TRY(hipSetDevice(d));
+        D->cacheKey.clear();  // whatever happens below, the old job's block is about to be overwritten
+        hipError_t e = D->arena.reserve(J.image.size());
+        if (e != hipSuccess) return fail(GRAFT_ERR_HIP, "hipMalloc(%zu) on device %d: %s", J.image.size(), d, hipGetErrorString(e));
+        HIP_TRY(hipMemcpy(D->arena.ptr, J.image.data(), J.image.size(), hipMemcpyHostToDevice));
+        if (!D->cacheJob) D->cacheJob = new (std::nothrow) GraftJob();
+        if (!D->cacheJob) return fail(GRAFT_ERR_HIP, "graftRenderFrameMulti: out of host memory");
+        describe(D->cacheJob, J, D->arena.ptr, false, D);
+        D->cacheKey = key;
+        jobs[d] = D->cacheJob;
+    }
     return GRAFT_OK;
 }
 
@@ -1298,80 +1454,85 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
         if (!view) return fail(GRAFT_ERR_ARG, "graftRenderFrameMulti: null view");
         return graftRenderRows(scene, view, 0, view->nRows, format, frameHost, hitIndexHost, countersHost);
     }
+    for (int d = 0; d < G; ++d)
+        if (!gDevices[d].comm || !gDevices[d].moveStream)
+            return fail(GRAFT_ERR_STATE, "graftRenderFrameMulti: device %d has no communicator (graftInitDevices failed?)", d);
     int rc = GRAFT_OK;
+    bool groupOpen = false;
     GraftJob *jobs[kMaxDevices] = {nullptr};
-    std::vector<int> first, count, owner;
-    std::vector<size_t> at;  // a piece's first row inside its owner's buffer
+    std::vector<int> first, count, owner, at;  // `at`: a piece's first row inside its owner's buffer
+    int ownedRows[kMaxDevices] = {0};
     GraftCounters sum = {0, 0, 0, 0};
     Device &root = gDevices[0];
     int nPieces = 0, rounds = 0, nCols = 0, nRows = 0;
-    size_t ownedRows[kMaxDevices] = {0};
-    // every device packs (or finds in its cache) the same job
-    for (int d = 0; d < G; ++d) {
-        HIP_GO(hipSetDevice(d));
-        if ((rc = cachedJob(&gDevices[d], scene, view, &jobs[d])) != GRAFT_OK) goto done;
-    }
+    // A trace that shares its GPU with RCCL's send/receive kernels leaves them a few CUs: without that the transfer of
+    // round c could only start when a persistent workgroup of round c + 1's trace retires, i.e. near its end.
+    const int reservedBefore = gSettings.reservedCUs;
+    if (gSettings.reservedCUs < kMultiReservedCUs) gSettings.reservedCUs = kMultiReservedCUs;
+    if ((rc = cachedJobs(G, scene, view, jobs)) != GRAFT_OK) goto done;
     nCols = jobs[0]->P.nCols;
     nRows = jobs[0]->P.nRows;
-    nPieces = graftFramePieces(nRows, G, piecesPerDevice, nullptr, nullptr, nullptr, 0);
+    nPieces = graftFramePlan(nRows, G, piecesPerDevice, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
     first.resize(nPieces); count.resize(nPieces); owner.resize(nPieces); at.resize(nPieces);
-    graftFramePieces(nRows, G, piecesPerDevice, first.data(), count.data(), owner.data(), nPieces);
-    for (int k = 0; k < nPieces; ++k) {
-        at[k] = ownedRows[owner[k]];
-        ownedRows[owner[k]] += (size_t)count[k];
-    }
+    graftFramePlan(nRows, G, piecesPerDevice, first.data(), count.data(), owner.data(), at.data(), ownedRows, nPieces);
     // buffers: the root holds the whole frame, every other device its own pieces
     for (int d = 0; d < G; ++d) {
         Device &D = gDevices[d];
         HIP_GO(hipSetDevice(d));
-        const size_t rowsHere = d == 0 ? (size_t)nRows : ownedRows[d];
+        const size_t rowsHere = d == 0 ? (size_t)nRows : (size_t)ownedRows[d];
         HIP_GO((d == 0 ? D.frame : D.pieces).reserve(rowsHere * nCols * pixelBytes + 16));
         if (hitIndexHost) HIP_GO((d == 0 ? D.index : D.pieceIndex).reserve(rowsHere * nCols * 4 + 16));
         if (countersHost) {
             HIP_GO(D.counters.reserve(sizeof(GraftCounters)));
             HIP_GO(hipMemsetAsync(D.counters.ptr, 0, sizeof(GraftCounters), D.stream));
         }
+        HIP_GO(hipEventRecord(D.frameStart, D.stream));
+        HIP_GO(hipEventRecord(D.kernelsDone, D.stream));  // (re-recorded behind every kernel)
     }
     // Round c: every device queues the kernel of its c-th piece; then one group of transfers moves the pieces of round
     // c to the root (each sender's transfer is ordered behind its kernel through its `traced` event and runs on its
-    // move stream, the root receives on its move stream), while the kernels of round c + 1 are already queued behind
-    // them on the trace streams: the transfers hide behind the tracing.
+    // move stream, the root receives on its move stream), while the kernels of round c + 1 are queued behind them on
+    // the trace streams and leave the transfer kernels their reserved CUs.
     rounds = (nPieces + G - 1) / G;
     for (int c = 0; c < rounds; ++c) {
         for (int k = c * G; k < nPieces && k < (c + 1) * G; ++k) {
             Device &D = gDevices[owner[k]];
             HIP_GO(hipSetDevice(D.id));
             unsigned char *frame = owner[k] == 0 ? (unsigned char *)D.frame.ptr + (size_t)first[k] * nCols * pixelBytes
-                                                 : (unsigned char *)D.pieces.ptr + at[k] * nCols * pixelBytes;
+                                                 : (unsigned char *)D.pieces.ptr + (size_t)at[k] * nCols * pixelBytes;
             int32_t *index = !hitIndexHost ? nullptr
                            : owner[k] == 0 ? (int32_t *)D.index.ptr + (size_t)first[k] * nCols
-                                           : (int32_t *)D.pieceIndex.ptr + at[k] * nCols;
+                                           : (int32_t *)D.pieceIndex.ptr + (size_t)at[k] * nCols;
             if ((rc = launchTrace(jobs[owner[k]], first[k], count[k], format, frame, index,
                                   countersHost ? (GraftCounters *)D.counters.ptr : nullptr, D.stream)) != GRAFT_OK) goto done;
+            HIP_GO(hipEventRecord(D.kernelsDone, D.stream));
             if (owner[k] != 0) {
                 HIP_GO(hipEventRecord(D.traced, D.stream));
                 HIP_GO(hipStreamWaitEvent(D.moveStream, D.traced, 0));
             }
         }
         NCCL_TRY(gRccl.groupStart());
+        groupOpen = true;
         for (int k = c * G; k < nPieces && k < (c + 1) * G; ++k) {
             if (owner[k] == 0) continue;
             Device &D = gDevices[owner[k]];
             const size_t bytes = (size_t)count[k] * nCols * pixelBytes;
-            NCCL_TRY(gRccl.send((unsigned char *)D.pieces.ptr + at[k] * nCols * pixelBytes, bytes, ncclChar, 0, D.comm, D.moveStream));
+            NCCL_TRY(gRccl.send((unsigned char *)D.pieces.ptr + (size_t)at[k] * nCols * pixelBytes, bytes, ncclChar, 0, D.comm, D.moveStream));
             NCCL_TRY(gRccl.recv((unsigned char *)root.frame.ptr + (size_t)first[k] * nCols * pixelBytes, bytes, ncclChar, owner[k],
                                 root.comm, root.moveStream));
             if (hitIndexHost) {
                 const size_t ib = (size_t)count[k] * nCols * 4;
-                NCCL_TRY(gRccl.send((int32_t *)D.pieceIndex.ptr + at[k] * nCols, ib, ncclChar, 0, D.comm, D.moveStream));
+                NCCL_TRY(gRccl.send((int32_t *)D.pieceIndex.ptr + (size_t)at[k] * nCols, ib, ncclChar, 0, D.comm, D.moveStream));
                 NCCL_TRY(gRccl.recv((int32_t *)root.index.ptr + (size_t)first[k] * nCols, ib, ncclChar, owner[k], root.comm, root.moveStream));
             }
         }
+        groupOpen = false;
         NCCL_TRY(gRccl.groupEnd());
     }
     // the assembled frame leaves the root once its own kernels and every transfer are done
     for (int d = 0; d < G; ++d) {
         HIP_GO(hipSetDevice(d));
+        HIP_GO(hipEventRecord(gDevices[d].movesDone, gDevices[d].moveStream));
         HIP_GO(hipStreamSynchronize(gDevices[d].stream));
         HIP_GO(hipStreamSynchronize(gDevices[d].moveStream));
         if (countersHost) {
@@ -1381,14 +1542,34 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
             sum.tests += c.tests;
             sum.raysTraced += c.raysTraced;
         }
+        // what graftMultiStats reports: this device's kernels from first to last, and how long after its last kernel
+        // its last transfer ended (the part of the exchange that tracing did not hide; negative: none)
+        HIP_GO(hipEventElapsedTime(&gMultiTraceMs[d], gDevices[d].frameStart, gDevices[d].kernelsDone));
+        HIP_GO(hipEventElapsedTime(&gMultiTailMs[d], gDevices[d].kernelsDone, gDevices[d].movesDone));
     }
+    gMultiStatsDevices = G;
     HIP_GO(hipSetDevice(0));
     HIP_GO(hipMemcpy(frameHost, root.frame.ptr, (size_t)nRows * nCols * pixelBytes, hipMemcpyDeviceToHost));
     if (hitIndexHost) HIP_GO(hipMemcpy(hitIndexHost, root.index.ptr, (size_t)nRows * nCols * 4, hipMemcpyDeviceToHost));
     if (countersHost) *countersHost = sum;
 done:
+    if (groupOpen) (void)gRccl.groupEnd();  // never leave a group open behind an error
+    if (rc != GRAFT_OK)
+        for (int d = 0; d < G; ++d) {  // let what was queued drain before the caller sees the error
+            (void)hipSetDevice(d);
+            if (gDevices[d].stream) (void)hipStreamSynchronize(gDevices[d].stream);
+            if (gDevices[d].moveStream) (void)hipStreamSynchronize(gDevices[d].moveStream);
+        }
+    gSettings.reservedCUs = reservedBefore;
     (void)hipSetDevice(0);
     return rc;
+}
+
+GRAFT_API int graftMultiStats(int device, float *traceMs, float *tailMs) {
+    if (device < 0 || device >= gMultiStatsDevices) return fail(GRAFT_ERR_ARG, "graftMultiStats: device %d took part in no multi-device frame", device);
+    if (traceMs) *traceMs = gMultiTraceMs[device];
+    if (tailMs) *tailMs = gMultiTailMs[device];
+    return GRAFT_OK;
 }
 
 static int probe(int which, const double *a, const double *b, double *out, size_t n) {

@@ -22,6 +22,7 @@ struct Settings {
     int screenCap = kMaxScreen;  // highest screen level a job may use
     int groupSize = 0;       // spheres per group of the two-level screens, 0 = chosen per scene
     int tilesPerTicket = 0;  // tiles a wave draws at once, 0 = chosen per launch
+    int reservedCUs = 0;     // CUs a trace's persistent grid leaves free (for transfer kernels running beside it)
 };
 
 struct PackedJob {
@@ -175,19 +176,32 @@ inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const 
         lists.push_back(&o.lists);
     }
     auto up = [](size_t x, size_t a) { return (x + a - 1) / a * a; };
-    const size_t oAos = 0, oExact = up(oAos + 16 * n, 32), oGroups = up(oExact + 32 * n, 16), oMembers = oGroups + 16 * G,
-                 oShape = oMembers + 16 * G * gs, oIndex = up(oShape + 2 * G * gs, 4), oPool = oIndex + 4 * n * nL;
+    const size_t entries = G + G * gs;  // group entries, then member entries
+    const size_t oAos = 0, oExact = up(oAos + 16 * n, 32), oGroups = up(oExact + 32 * n, 16), oSines = oGroups + 16 * entries,
+                 oShape = oSines + 4 * entries, oIndex = up(oShape + 2 * G * gs, 4), oPool = oIndex + 4 * n * nL;
     size_t poolEntries = n;  // the list of all spheres comes first
     std::vector<size_t> base(nL);
     for (size_t i = 0; i < nL; ++i) { base[i] = poolEntries; poolEntries += lists[i]->pool.size(); }
     if (poolEntries >= (1u << 20)) return false;
     const size_t blob = up(oPool + 2 * poolEntries, 16);
+    // behind the image: a tile list per wave and, where it fits, the waves' tables of sample scale factors
+    // (launches of fewer than four samples per pixel run kernels that do not look at the table: launchTrace)
+    const bool wantSamples = view->aliasing && view->numPasses >= 2 && view->numPasses <= kSampleTablePasses;
+    const size_t perWave = 2 * kTileListCap, perWaveSamples = 8 * 16 * (size_t)(wantSamples ? view->numPasses : 0);
     block = 0;
-    for (int b = kSmallBlock; b <= kLargeBlock; b *= 2) {
-        const size_t total = blob + (size_t)(b / 64) * 2 * kTileListCap;
-        const size_t limit = b == kSmallBlock ? kLdsSmall : b == 2 * kSmallBlock ? 2 * kLdsSmall : kLdsMax;
-        if (total <= limit) { block = b; ldsBytes = total; break; }
-    }
+    P.sampleTableOff = -1;
+    for (int withSamples = wantSamples ? 1 : 0; withSamples >= 0 && !block; --withSamples)
+        for (int b = kSmallBlock; b <= kLargeBlock; b *= 2) {
+            const size_t waves = (size_t)(b / 64);
+            const size_t total = blob + waves * perWave + (withSamples ? waves * perWaveSamples : 0);
+            const size_t limit = b == kSmallBlock ? kLdsSmall : b == 2 * kSmallBlock ? 2 * kLdsSmall : kLdsMax;
+            if (total <= limit) {
+                block = b;
+                ldsBytes = total;
+                if (withSamples) P.sampleTableOff = (int)(blob + waves * perWave);
+                break;
+            }
+        }
     if (!block) return false;
     std::vector<unsigned char> lds(blob, 0);
     for (size_t k = 0; k < n; ++k) {
@@ -196,11 +210,27 @@ inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const 
         memcpy(&lds[oAos + 16 * k], e, sizeof e);
     }
     memcpy(&lds[oExact], sph.data(), 32 * n);
-    std::vector<float> plain;
-    unpackEntries(cam.entries, 0, G, plain);
-    memcpy(&lds[oGroups], plain.data(), 16 * G);
-    unpackEntries(cam.entries, (size_t)cam.memberBase, G * gs, plain);
-    memcpy(&lds[oMembers], plain.data(), 16 * G * gs);
+    // cone entries as {axis, cos A'} and sin A', from the table's -kappa2 = -(cos^2 A'): the cosine rounded down, the
+    // sine up (either way the cone only widens); an entry that always passes gets cos = -2, one that never does +inf
+    auto coneEntries = [&](size_t first, size_t count, size_t at) {
+        std::vector<float> plain;
+        unpackEntries(cam.entries, first, count, plain);
+        for (size_t e = 0; e < count; ++e) {
+            const double k2 = -(double)plain[4 * e + 3];
+            float c = INFINITY, sn = 0.0f;
+            if (k2 < 0) {
+                c = -2.0f;
+            } else if (k2 <= 1.0) {
+                c = floatBelow(sqrt(k2) * (1.0 - 1e-12));
+                sn = -floatBelow(-sqrt(1.0 - (double)c * (double)c) * (1.0 + 1e-12));
+            }
+            plain[4 * e + 3] = c;
+            memcpy(&lds[oGroups + 16 * (at + e)], &plain[4 * e], 16);
+            memcpy(&lds[oSines + 4 * (at + e)], &sn, 4);
+        }
+    };
+    coneEntries(0, G, 0);
+    coneEntries((size_t)cam.memberBase, G * gs, G);
     for (size_t m = 0; m < G * gs; ++m) {
         const unsigned short id = cam.memberShape[m] < 0 ? (unsigned short)0xffff : (unsigned short)cam.memberShape[m];
         memcpy(&lds[oShape + 2 * m], &id, 2);
@@ -221,7 +251,7 @@ inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const 
     memcpy(image.data(), lds.data(), blob);
     P.exactLdsOffset = (int)oExact;
     P.listGroups = (int)G;
-    P.listGroupsOff = (int)oGroups; P.listMembersOff = (int)oMembers; P.listShapeOff = (int)oShape;
+    P.listGroupsOff = (int)oGroups; P.listSinesOff = (int)oSines; P.listShapeOff = (int)oShape;
     P.listIndexOff = (int)oIndex; P.listPoolOff = (int)oPool; P.listTileOff = (int)blob;
     return true;
 }
@@ -485,8 +515,10 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     host.assign(total, 0);
     if (!sph.empty()) memcpy(&host[J.oGeom], sph.data(), sizeof(double) * sph.size());
     if (!pln.empty()) memcpy(&host[J.oGeom + sizeof(double) * sph.size()], pln.data(), sizeof(double) * pln.size());
-    for (int i = 0; i < kGeomPad; i += 4) {  // padding spheres that every ray misses: r*r = -inf
-        const double never[4] = {0, 0, 0, -INFINITY};
+    // padding spheres that every ray misses: a large negative FINITE r*r, so that the discriminant is a negative finite
+    // number and the block test of the exact loop (is any of four values not negative and finite?) passes over them
+    for (int i = 0; i < kGeomPad; i += 4) {
+        const double never[4] = {0, 0, 0, -1e300};
         memcpy(&host[J.oGeom + sizeof(double) * (P.geomDoubles + i)], never, sizeof never);
     }
     if (!tableF.empty()) memcpy(&host[J.oGeomF], tableF.data(), sizeof(float) * tableF.size());

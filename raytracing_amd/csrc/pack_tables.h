@@ -436,8 +436,9 @@ inline void unpackEntries(const std::vector<float> &packed, size_t first, size_t
 // with the reference's arithmetic as ever.  What is closest among the listed spheres is then either the reference's
 // closest hit (if that lies before the light) or lies beyond the light whenever the reference's does.
 // Shapes on the light's avoid list (mainTracing.c:134, :210) are left out here, once, instead of being compared
-// per ray.  Entries are sphere numbers (16 bits); list (k) = pool[index[k] & 0xfffff ...], length index[k] >> 20,
-// length kListAll standing for "every sphere".  Returns false when the scene does not qualify.
+// per ray; so is sphere k itself, which the walk looks at first (closestHitLists).  Entries are sphere numbers
+// (16 bits); list (k) = pool[index[k] & 0xfffff ...], length index[k] >> 20, length kListAll standing for "every
+// sphere, k included" (only for lights that avoid nothing).  Returns false when the scene does not qualify.
 constexpr unsigned kListAll = 4095;
 struct LightLists {
     std::vector<unsigned> index;        // per sphere: offset into pool | length << 20
@@ -479,12 +480,13 @@ inline bool packLightLists(const std::vector<double> &sph, const double light[3]
     std::vector<unsigned short> list;
     for (int k = 0; k < n; ++k) {
         list.clear();
-        bool all = wideB[k] != 0;
+        bool all = wideB[k] != 0 && !avoidRow;  // (with an avoid list the list of everything else is written out)
         const double *uk = &dir[3 * (size_t)k];
         const double reach = (dist[k] + rad[k] + grow[k]) * (1 + 1e-12);
+        const bool everything = wideB[k] != 0;  // no bound on where its shadow rays go: every sphere is a candidate
         for (int j = 0; j < n && !all; ++j) {
-            if (avoidRow && avoidRow[j]) continue;
-            if (!wideA[j]) {
+            if (j == k || (avoidRow && avoidRow[j])) continue;
+            if (!wideA[j] && !everything) {
                 const double *uj = &dir[3 * (size_t)j];
                 const double c = uj[0] * uk[0] + uj[1] * uk[1] + uj[2] * uk[2];
                 // cos(A_j + B_k); both angles are below kWide, so the sum is below pi and the cosine decreases
@@ -493,7 +495,10 @@ inline bool packLightLists(const std::vector<double> &sph, const double light[3]
                 if (dist[j] - rad[j] > reach && c > 0.5 && cosA[j] > 0.9 && cosB[k] > 0.9) continue;
             }
             list.push_back((unsigned short)j);
-            if (list.size() >= kListAll) all = true;
+            if (list.size() >= kListAll) {
+                if (avoidRow) return false;  // (too long to write out, and the list of all spheres would undo the avoid list)
+                all = true;
+            }
         }
         if (all) {
             T.index[k] = kListAll << 20;

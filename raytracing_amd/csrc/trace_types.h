@@ -25,6 +25,7 @@ constexpr int kCursors = 16;        // ticket counters of the many-counter kerne
 constexpr int kCursorStride = 32;   // ... one per 128-byte line
 constexpr size_t kLdsSmall = 36 * 1024;
 constexpr size_t kLdsMax = 152 * 1024;
+constexpr int kSampleTablePasses = 8;  // supersampling up to this many passes keeps per-tile scale factors in LDS
 constexpr int kTileListCap = 128;   // entries of a wave's tile list (closestHitLists); longer lists fall back to all spheres
 
 struct DevRun {  // shapes [firstShape, firstShape+count) are all of `kind`; their geometry starts at slot
@@ -115,10 +116,13 @@ struct TraceParams {
     const DevGrid *grid;
     // SCREEN == 6 (candidate lists, closestHitLists): the LDS image is the first filterFloats floats of geomF, laid out
     // as {sphere screen table [numSpheres] float4 | exact doubles at exactLdsOffset | camera cone table: listGroups
-    // group entries, listGroups * groupSize member entries (float4 each) and the members' sphere numbers (16 bits) |
-    // occluder-list index [numSpheres][numLights] | list pool (16-bit sphere numbers; the list of all spheres first) |
-    // one tile list of kTileListCap entries per wave of the workgroup}; byte offsets from the start of LDS
-    int listGroups, listGroupsOff, listMembersOff, listShapeOff, listIndexOff, listPoolOff, listTileOff;
+    // group entries then listGroups * groupSize member entries, as {axis, cos} float4 at listGroupsOff and their sines
+    // (float) at listSinesOff, and the members' sphere numbers (16 bits) at listShapeOff | occluder-list index
+    // [numSpheres][numLights] | list pool (16-bit sphere numbers; the list of all spheres first) | one tile list of
+    // kTileListCap entries per wave of the workgroup | with supersampling of at most kSampleTablePasses passes: per
+    // wave 16 * numPasses doubles, the scale factors of the tile's columns and rows (sampleTableOff, else -1)}; byte
+    // offsets from the start of LDS
+    int listGroups, listGroupsOff, listSinesOff, listShapeOff, listIndexOff, listPoolOff, listTileOff, sampleTableOff;
     const int *memberShape;    // grouped screen: shape index of every member-table entry, -1 = padding
     const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
     const double *geom;

@@ -52,14 +52,34 @@ def frame_pieces(n_rows, n_devices, pieces_per_device):
     return [(a[i], b[i], c[i]) for i in range(cap)]
 
 
+def frame_plan(n_rows, n_devices, pieces_per_device):
+    """graftFramePlan: (pieces, owned rows per device); a piece is (first row, rows, owner device, first row inside
+    the owner's own buffer)."""
+    cap = lib.graftFramePlan(int(n_rows), int(n_devices), int(pieces_per_device), None, None, None, None, None, 0)
+    if cap < 0:
+        raise ValueError("bad frame or device count")
+    a, b, c, d = ((ctypes.c_int32 * max(cap, 1))() for _ in range(4))
+    owned = (ctypes.c_int32 * int(n_devices))()
+    lib.graftFramePlan(int(n_rows), int(n_devices), int(pieces_per_device), a, b, c, d, owned, cap)
+    return [(a[i], b[i], c[i], d[i]) for i in range(cap)], list(owned)
+
+
+def multi_stats(device):
+    """graftMultiStats: (ms from the device's first kernel to its last, ms from its last kernel to its last transfer)
+    of the last multi-device frame."""
+    t, tail = ctypes.c_float(), ctypes.c_float()
+    check(lib.graftMultiStats(int(device), ctypes.byref(t), ctypes.byref(tail)))
+    return t.value, tail.value
+
+
 def device_count():
     n = lib.graftDeviceCount()
     return max(n, 0)
 
 
 def set_diagnostic(name, value):
-    """graftDiagnosticSet: "screen_cap" 0..6, "group_size" 0|4..64, "tiles_per_ticket" (A/B timing and tests;
-    no setting changes a result).  Returns the previous value."""
+    """graftDiagnosticSet: "screen_cap" 0..6, "group_size" 0|4..64, "tiles_per_ticket", "reserved_cus" (A/B timing,
+    tests, and room for transfer kernels beside a trace; no setting changes a result).  Returns the previous value."""
     which = _lib.DIAGNOSTICS[name]
     old = lib.graftDiagnosticGet(which)
     check(lib.graftDiagnosticSet(which, int(value)))

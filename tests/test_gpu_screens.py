@@ -193,6 +193,18 @@ def test_large_scenes_three_level_walk(gpu):
     check_all_levels(rt, levels=(0, 4, 5))
 
 
+def test_grid_walk_far_from_the_scene(gpu):
+    """An orthographic view whose screen plane lies tens of thousands of units from a compact scene: every primary
+    ray enters the grid at a ray parameter of about 3e4, where single precision resolves 2e-3 -- the walk must step
+    relative to its entry point, or cells that list the sphere hit are skipped."""
+    rt = large_scene(35, 1500, projection=ORTHOGRAPHIC, lights=7, refl=0.5, depth=3)
+    rt.sceneInitialize([0.0, 0.0, 0.0], 30000.0, 1000.0)
+    check_all_levels(rt, levels=(0, 5))
+    rt.rotateView(0.7, [0.3, 1.0, 0.1])
+    rt.rotateView(-0.4, list(rt.lrVec))
+    check_all_levels(rt, levels=(0, 5))
+
+
 def test_groups_of_sixteen_and_other_sizes(gpu):
     """Scenes of 512+ spheres whose tables fit in LDS use 16 spheres per group; GRAFT_GROUP forces other sizes."""
     rt = large_scene(33, 600, lights=3, refl=0.4, depth=3)
@@ -228,6 +240,9 @@ def test_levels_are_actually_used(gpu):
     assert level(matte(large_scene(33, 600, lights=3))) == 6
     assert level(scene(11, 130, projection=ORTHOGRAPHIC)) == 3    # no camera to build tile lists around
     assert level(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7)) == 5
+    far = large_scene(35, 1500, projection=ORTHOGRAPHIC, lights=7, refl=0.5, depth=3)
+    far.sceneInitialize([0.0, 0.0, 0.0], 30000.0, 1000.0)
+    assert level(far) == 5
     assert level(scene(20, 100, lights=9)) == 2          # too many lights for the family tables
     assert level(scene(1, 40)) == 1                      # too few spheres for grouping
     assert level(scenes.default_scene()) == 1            # planes: per-sphere screen only

@@ -102,3 +102,31 @@ def test_c_piece_list_equals_the_python_one(rows, world, chunks):
     assert got[0][0] == 0 and sum(n for _, n, _ in got) == rows
     for (a, n, _), (b, _, _) in zip(got, got[1:]):
         assert a + n == b and a % 8 == 0
+
+
+@pytest.mark.parametrize("rows", [16384, 8192, 4097, 513, 100, 64, 9, 8, 1])
+@pytest.mark.parametrize("devices", [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("per_device", [1, 3, 8, 16])
+def test_c_frame_plan(rows, devices, per_device):
+    """graftFramePlan (where graftRenderFrameMulti puts every piece): pieces cover every row once, in order; a device's
+    pieces lie back to back in its own buffer, in the order they are traced; the buffer sizes are the sums; and the
+    whole plan equals what every rank of the one-process-per-GPU path derives for itself (owned_pieces)."""
+    from raytracing_amd import frame_pieces as c_pieces, frame_plan
+    from raytracing_amd.distributed import local_rows, owned_pieces
+    pieces, owned = frame_plan(rows, devices, per_device)
+    assert [(a, n, o) for a, n, o, _ in pieces] == c_pieces(rows, devices, per_device)
+    assert pieces[0][0] == 0 and sum(n for _, n, _, _ in pieces) == rows and len(owned) == devices
+    covered = np.zeros(rows, dtype=int)
+    for first, n, owner, at in pieces:
+        assert n > 0 and 0 <= owner < devices and first % 8 == 0
+        covered[first:first + n] += 1
+    assert (covered == 1).all()
+    for d in range(devices):
+        mine = [(first, n, at) for first, n, owner, at in pieces if owner == d]
+        assert mine == owned_pieces(rows, devices, d, per_device)
+        at = 0
+        for _, n, where in mine:          # disjoint, gap-free, in tracing order
+            assert where == at
+            at += n
+        assert owned[d] == at == local_rows(rows, devices, d, per_device)
+    # with an index plane the same row offsets address 4-byte entries: nothing else to plan
