@@ -964,7 +964,8 @@ __device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles 
     return count <= kTileListCap ? count : -1;
 }
 
-// Closest hit among the spheres of the lane's list: `len` sphere numbers from pool[pos] on (LDS).  One candidate is
+// Closest hit among the spheres of the lane's list: `len` sphere numbers from chunk `pos` of the pool on (LDS; a
+// chunk is four 16-bit numbers, fetched with one read and used up over four trips).  One candidate is
 // parked per lane and the exact test runs, for every lane that has one parked, when some lane needs the slot again
 // or has reached the end of its list -- one code site, shared by lanes whose lists differ.  Spheres are met out of
 // index order: see closestHitGrouped for why the winner does not depend on it.
@@ -975,7 +976,9 @@ __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx,
                                                 double dz, int pos, int len, int self, float negThreshold, Hit &h) {
     const float4v *aos = (const float4v *)ldsGeom;
     const double4v *geom = (const double4v *)((const char *)ldsGeom + P.exactLdsOffset);
-    const unsigned short *pool = (const unsigned short *)((const char *)ldsGeom + P.listPoolOff);
+    const unsigned long long *pool = (const unsigned long long *)((const char *)ldsGeom + P.listPoolOff);
+    unsigned long long chunk = 0;
+    int trip = 0;
     Best closest = {0, -1, -1};
     const double slackBase = fabs(sx) + fabs(sy) + fabs(sz);
     const double dd = dx * dx + dy * dy + dz * dz;
@@ -993,8 +996,11 @@ __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx,
     }
     while (__ballot(len > 0 || pending >= 0)) {
         int j = -1;
+        if ((trip & 3) == 0 && len > 0) chunk = pool[pos++];  // (the trip count is the same for all lanes)
+        ++trip;
         if (len > 0) {
-            const int k = pool[pos];
+            const int k = (int)(chunk & 0xffffu);
+            chunk >>= 16;
             const float4v e = aos[k];
             // single-precision screen (closestHitScreened's arithmetic): below the threshold = exact discriminant negative
             const float vx = sxf - e.x, vy = syf - e.y, vz = szf - e.z;
@@ -1006,7 +1012,6 @@ __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx,
             vv = __builtin_fmaf(vz, vz, vv);
             if (!(__builtin_fmaf(b, b, e.w - vv) < negThreshold)) j = k;
         }
-        ++pos;
         --len;
         if (__ballot(pending >= 0 && (j >= 0 || len <= 0))) {
             if (pending >= 0) {

@@ -101,9 +101,9 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     const unsigned long long stampBegin = clock64();
 #endif
 
-    // SCREEN == 6: where the wave's tile list starts in the list pool (in LDS, one list per wave of the workgroup) and
-    // how long the current tile's is (kListAll: every sphere)
-    const int tileListPos = SCREEN == 6 ? ((P.listTileOff - P.listPoolOff) >> 1) + (int)(threadIdx.x >> 6) * kTileListCap : 0;
+    // SCREEN == 6: where the wave's tile list starts in the list pool (in LDS, one list per wave of the workgroup; in
+    // chunks of four entries) and how long the current tile's is (kListAll: every sphere)
+    const int tileListPos = SCREEN == 6 ? ((P.listTileOff - P.listPoolOff) >> 3) + (int)(threadIdx.x >> 6) * (kTileListCap / 4) : 0;
     int tileListLen = 0;
 
     // rayIntersectAvoid for one ray per lane (mainTracing.c:128-153): picks the walk the job was built for; returns
@@ -118,7 +118,23 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             if (AVOID == 1) avoidShape = L.avoidFirst;
             if (AVOID == 2 && L.avoidNum > 0) avoidRow = P.avoidMask + (size_t)li * P.numShapes;
         }
-        if (SCREEN) {
+        if (SCREEN == 6 && AVOID == 0) {
+            // Level 6 in a scene whose lights avoid nothing: one walk for every ray.  A ray that starts beyond the
+            // scale the lists were built for (none does in a job that qualifies) looks at every sphere, behind the
+            // single-precision screen alone, whose threshold never proves anything for coordinates it cannot bound.
+            const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
+            const float negThreshold = s1 < 1e15 ? -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001) : -INFINITY;
+            int pos = tileListPos, len = tileListLen, self = -1;
+            if (mode == M_SHADOW) {
+                const unsigned *index = (const unsigned *)((const char *)ldsGeom + P.listIndexOff);
+                const unsigned w = index[from * P.numLights + li];
+                pos = (int)(w & 0xfffffu);
+                len = (int)(w >> 20);
+                self = from;
+            }
+            if (len == (int)kListAll || !(s1 < P.familyScale)) { pos = 0; len = P.numSpheres; self = -1; }  // (the pool starts with every sphere)
+            closestHitLists(P, o[0], o[1], o[2], d[0], d[1], d[2], pos, len, self, negThreshold, h);
+        } else if (SCREEN) {
             const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
             // (level 6: every direction comes out of vecUnit -- unit length or the zero vector -- and every origin is a
             // screen point or a point of a sphere, all finite in a job that qualifies; the test on the origin stays)
@@ -455,7 +471,26 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 }
 
                 GRAFT_STAGE(0);  // what the query found: hit (normal, lights in front) or shadow result
-                if (finalize) {  // mainTracing.c:330-369 for the level whose hit is (hitIdx, loc, nrm, din)
+                if (!MIRRORS && !TRANSP && finalize) {  // mainTracing.c:352-369 for a hit without children
+                    const DevShade &m = P.shade[hitIdx];
+                    double light[3] = {0, 0, 0};
+                    if (litLight >= 0) {  // the last unshadowed light overwrites, mainTracing.c:223-225
+                        const DevLight &L = P.lights[litLight];
+                        for (int c = 0; c < 3; ++c) {
+                            double t = L.color[c] * m.color[c];
+                            light[c] = litW * t;
+                        }
+                    }
+                    for (int c = 0; c < 3; ++c) {
+                        const double lit = m.wDiff * light[c];
+                        const double part = lit + m.ambient[c];
+                        double out = m.mirrorZero + part;  // reflectionRGB and refractionRGB stay {0,0,0}
+                        out = (0.0 * 0.0) + out;
+                        v[c] = out;
+                    }
+                    unwind = true;
+                }
+                if ((MIRRORS || TRANSP) && finalize) {  // mainTracing.c:330-369 for the level whose hit is (hitIdx, loc, nrm, din)
                     const DevMaterial &m = P.materials[hitIdx];
                     const double rgb[3] = {m.color[0], m.color[1], m.color[2]};
                     double light[3] = {0, 0, 0};

@@ -28,7 +28,7 @@ struct Settings {
 struct PackedJob {
     TraceParams P;                     // everything but the pointers, which bindImage() fills in
     std::vector<unsigned char> image;  // the device block, byte for byte
-    size_t oGeom = 0, oGeomF = 0, oMember = 0, oRuns = 0, oMat = 0, oLights = 0, oMask = 0, oCol = 0, oRow = 0,
+    size_t oGeom = 0, oGeomF = 0, oMember = 0, oRuns = 0, oMat = 0, oShade = 0, oLights = 0, oMask = 0, oCol = 0, oRow = 0,
            oCam = 0, oGrid = 0, oCursor = 0;
     int avoidMode = 0;
     int screen = 0;         // 0 = exact only, 1 = screen per sphere, 2 = two-level ball screen, 3/4 = per-family screens
@@ -178,11 +178,11 @@ inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const 
     auto up = [](size_t x, size_t a) { return (x + a - 1) / a * a; };
     const size_t entries = G + G * gs;  // group entries, then member entries
     const size_t oAos = 0, oExact = up(oAos + 16 * n, 32), oGroups = up(oExact + 32 * n, 16), oSines = oGroups + 16 * entries,
-                 oShape = oSines + 4 * entries, oIndex = up(oShape + 2 * G * gs, 4), oPool = oIndex + 4 * n * nL;
-    size_t poolEntries = n;  // the list of all spheres comes first
+                 oShape = oSines + 4 * entries, oIndex = up(oShape + 2 * G * gs, 4), oPool = up(oIndex + 4 * n * nL, 8);
+    size_t poolEntries = up(n, 4);  // the list of all spheres comes first; every list starts at a multiple of 4 entries
     std::vector<size_t> base(nL);
     for (size_t i = 0; i < nL; ++i) { base[i] = poolEntries; poolEntries += lists[i]->pool.size(); }
-    if (poolEntries >= (1u << 20)) return false;
+    if (poolEntries / 4 >= (1u << 20)) return false;
     const size_t blob = up(oPool + 2 * poolEntries, 16);
     // behind the image: a tile list per wave and, where it fits, the waves' tables of sample scale factors
     // (launches of fewer than four samples per pixel run kernels that do not look at the table: launchTrace)
@@ -238,7 +238,7 @@ inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const 
     for (size_t k = 0; k < n; ++k)
         for (size_t i = 0; i < nL; ++i) {
             unsigned w = lists[i]->index[k];
-            if ((w >> 20) != kListAll) w += (unsigned)base[i];  // (offsets stay below 2^20: checked above)
+            if ((w >> 20) != kListAll) w += (unsigned)(base[i] / 4);  // (chunk numbers stay below 2^20: checked above)
             memcpy(&lds[oIndex + 4 * (k * nL + i)], &w, 4);
         }
     for (size_t k = 0; k < n; ++k) {
@@ -503,7 +503,8 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     J.oMember = align(J.oGeomF + sizeof(float) * (tableF.size() + 1));
     J.oRuns = align(J.oMember + sizeof(int) * (memberShape.size() + 1));
     J.oMat = align(J.oRuns + sizeof(DevRun) * (runs.size() + 1));
-    J.oLights = align(J.oMat + sizeof(DevMaterial) * (nS + 1));
+    J.oShade = align(J.oMat + sizeof(DevMaterial) * (nS + 1));
+    J.oLights = align(J.oShade + sizeof(DevShade) * (nS + 1));
     J.oMask = align(J.oLights + sizeof(DevLight) * (nL + 1));
     J.oCol = align(J.oMask + mask.size() + 1);
     J.oRow = align(J.oCol + sizeof(double) * view->nCols);
@@ -525,6 +526,19 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     if (!memberShape.empty()) memcpy(&host[J.oMember], memberShape.data(), sizeof(int) * memberShape.size());
     if (!runs.empty()) memcpy(&host[J.oRuns], runs.data(), sizeof(DevRun) * runs.size());
     if (nS) memcpy(&host[J.oMat], mats.data(), sizeof(DevMaterial) * nS);
+    for (int k = 0; k < nS; ++k) {  // (this file is compiled without contraction of multiply and add, like the kernels)
+        const DevMaterial &m = mats[k];
+        DevShade sh;
+        for (int c = 0; c < 3; ++c) {
+            sh.color[c] = m.color[c];
+            const double amb = m.ambientLight * m.color[c];
+            sh.ambient[c] = amb + 0.0;
+        }
+        sh.wDiff = (1 - m.ambientLight) * (1 - m.reflectivity) * (1 - m.transparency);
+        const double wRefl = (1 - m.ambientLight) * m.reflectivity;
+        sh.mirrorZero = wRefl * 0.0;
+        memcpy(&host[J.oShade + sizeof(DevShade) * k], &sh, sizeof sh);
+    }
     if (nL) memcpy(&host[J.oLights], lights.data(), sizeof(DevLight) * nL);
     if (!mask.empty()) memcpy(&host[J.oMask], mask.data(), mask.size());
     memcpy(&host[J.oCol], view->colOffsets, sizeof(double) * view->nCols);
@@ -566,6 +580,7 @@ inline TraceParams bindImage(const PackedJob &J, void *base) {
     P.memberShape = (const int *)(b + J.oMember);
     P.runs = (const DevRun *)(b + J.oRuns);
     P.materials = (const DevMaterial *)(b + J.oMat);
+    P.shade = (const DevShade *)(b + J.oShade);
     P.lights = (const DevLight *)(b + J.oLights);
     P.avoidMask = (const unsigned char *)(b + J.oMask);
     P.colOff = (const double *)(b + J.oCol);

@@ -437,12 +437,13 @@ inline void unpackEntries(const std::vector<float> &packed, size_t first, size_t
 // closest hit (if that lies before the light) or lies beyond the light whenever the reference's does.
 // Shapes on the light's avoid list (mainTracing.c:134, :210) are left out here, once, instead of being compared
 // per ray; so is sphere k itself, which the walk looks at first (closestHitLists).  Entries are sphere numbers
-// (16 bits); list (k) = pool[index[k] & 0xfffff ...], length index[k] >> 20, length kListAll standing for "every
-// sphere, k included" (only for lights that avoid nothing).  Returns false when the scene does not qualify.
+// (16 bits), read four at a time: every list starts at a multiple of four entries (a CHUNK of 8 bytes); list (k)
+// starts at chunk index[k] & 0xfffff and has index[k] >> 20 entries, length kListAll standing for "every sphere, k
+// included" (only for lights that avoid nothing).  Returns false when the scene does not qualify.
 constexpr unsigned kListAll = 4095;
 struct LightLists {
-    std::vector<unsigned> index;        // per sphere: offset into pool | length << 20
-    std::vector<unsigned short> pool;
+    std::vector<unsigned> index;        // per sphere: first chunk in pool | length << 20
+    std::vector<unsigned short> pool;   // (a multiple of 4 entries)
 };
 
 inline bool packLightLists(const std::vector<double> &sph, const double light[3], double scale,
@@ -503,9 +504,10 @@ inline bool packLightLists(const std::vector<double> &sph, const double light[3]
         if (all) {
             T.index[k] = kListAll << 20;
         } else {
-            if (T.pool.size() + list.size() >= (1u << 20)) return false;
-            T.index[k] = (unsigned)T.pool.size() | ((unsigned)list.size() << 20);
+            if ((T.pool.size() + list.size()) / 4 + 1 >= (1u << 20)) return false;
+            T.index[k] = (unsigned)(T.pool.size() / 4) | ((unsigned)list.size() << 20);
             T.pool.insert(T.pool.end(), list.begin(), list.end());
+            T.pool.resize((T.pool.size() + 3) / 4 * 4, 0);
         }
     }
     return true;

@@ -41,6 +41,18 @@ struct DevMaterial {  // 64 bytes per shape
     int slot, kind;
 };
 
+// What the shading of a hit WITHOUT children needs (scenes without mirrors or transparent shapes), formed on the host
+// with the reference's own operations (mainTracing.c:352-369), which depend on the shape alone:
+// wDiff = (1 - ambient)(1 - reflectivity)(1 - transparency), ambient[c] = ambientLight * color[c] + 0.0,
+// mirrorZero = ((1 - ambient) * reflectivity) * 0.0 -- the reflection term of a hit that reflects nothing: a zero whose
+// sign the sum still sees.
+struct DevShade {  // 64 bytes per shape
+    double color[3];
+    double wDiff;
+    double ambient[3];
+    double mirrorZero;
+};
+
 struct DevLight {  // 64 bytes per light
     double color[3];
     double loc[3];
@@ -128,6 +140,7 @@ struct TraceParams {
     const double *geom;
     const DevRun *runs;
     const DevMaterial *materials;
+    const DevShade *shade;
     const DevLight *lights;
     const unsigned char *avoidMask;  // [numLights][numShapes], avoid mode 2 only
     const double *colOff, *rowOff;
