@@ -217,7 +217,7 @@ def recorded_counters(workload, frame, screen_cap):
     """What the hardware counters said about this same command (profiles/collect_pmc.sh + summarize_pmc.py):
     profiles/pmc_<workload>[_level<cap>].json.  Returns (record, note): the record is used only when it was taken
     on this frame size; the note says whether it belongs to the build that is running."""
-    name = "pmc_%s%s.json" % (workload, "" if screen_cap >= 6 else "_level%d" % screen_cap)
+    name = "pmc_%s%s.json" % (workload, "" if screen_cap >= 7 else "_level%d" % screen_cap)
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             rec = json.load(f)
@@ -298,7 +298,7 @@ def main():
     ap.add_argument("--workload", default="cfg4")
     ap.add_argument("--width", type=int, default=None, help="reduced frame width (debugging)")
     ap.add_argument("--height", type=int, default=None, help="reduced frame height (debugging)")
-    ap.add_argument("--screen", type=int, default=6, help="cap of the screen level (0 = the exact double loop only)")
+    ap.add_argument("--screen", type=int, default=7, help="cap of the screen level (0 = the exact double loop only)")
     ap.add_argument("--cpu-rows", type=int, default=None, help="rows of the frame the CPU baseline traces")
     ap.add_argument("--cpu-cores", type=int, default=None, help="host threads of the CPU baseline (default: all this "
                     "process may use)")

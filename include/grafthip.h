@@ -135,7 +135,7 @@ GRAFT_API const char *graftLastError(void);
  * graftDiagnosticGet reports the values in force.  A setting applies to jobs created (SCREEN_CAP, GROUP_SIZE) or
  * traces queued (TILES_PER_TICKET) after the call.  (No reference counterpart.) */
 enum {
-    GRAFT_DIAG_SCREEN_CAP = 0,       /* 0..6: highest screen level a job may use (graftJobScreenLevel); default 6 */
+    GRAFT_DIAG_SCREEN_CAP = 0,       /* 0..7: highest screen level a job may use (graftJobScreenLevel); default 7 */
     GRAFT_DIAG_GROUP_SIZE = 1,       /* spheres per group of the two-level screens: 0 = chosen per scene, else 4..64, a multiple of 4 */
     GRAFT_DIAG_TILES_PER_TICKET = 2, /* 8x8 tiles a wave draws from the ticket counters at once: 0 = chosen per launch */
     GRAFT_DIAG_TABLE_BUILDS = 4,     /* read-only: screen tables built so far (shows what a re-render re-used) */
@@ -179,7 +179,7 @@ GRAFT_API void graftJobDestroy(GraftJob *job);
  * 0 = none (exact double loop), 1 = single-precision screen per sphere, 2 = two-level ball screen, 3 = two-level
  * screens per ray family, 4 = three levels with cone member sections in global memory, 5 = level 4 with a uniform
  * grid for the rays behind a mirror, 6 = candidate lists (per tile for primary rays, per sphere and light for shadow
- * rays).  -1 for a null job. */
+ * rays) in LDS, 7 = candidate lists in global memory plus the grid for the rays behind a mirror.  -1 for a null job. */
 GRAFT_API int graftJobScreenLevel(const GraftJob *job);
 
 /* Trace loop rows [row0, row0+nRows) of the job's frame into DEVICE memory: `frame` holds nRows*nCols pixels

@@ -1,10 +1,10 @@
 #!/bin/bash
 # A/B timing of two builds of the library on one box: bash profiles/ab_libs.sh <other .so> [workloads...]
-# Prints kernel milliseconds per workload for the in-tree library (screen cap $CAP, default 6) and for the other one
+# Prints kernel milliseconds per workload for the in-tree library (screen cap $CAP, default 7) and for the other one
 # (screen cap $OTHER_CAP, default $CAP), alternating, $REPS times each (default 2).
 OTHER=$1; shift
 WLS=${@:-"cfg3 cfg4 cfg5"}
-CAP=${CAP:-6}
+CAP=${CAP:-7}
 OTHER_CAP=${OTHER_CAP:-$CAP}
 for wl in $WLS; do
   for rep in $(seq 1 ${REPS:-2}); do

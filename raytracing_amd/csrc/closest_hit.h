@@ -870,7 +870,7 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
     finishBest(closest, sx, sy, sz, dx, dy, dz, h);
 }
 
-// ---- candidate lists (SCREEN == 6) ------------------------------------------------------------------------------
+// ---- candidate lists (SCREEN == 6, 7) ---------------------------------------------------------------------------
 //
 // Sphere-only scenes seen in perspective.  Every ray of the path passes through a point that is known before the ray
 // is: a primary ray through the camera, a shadow ray through its light AND through a point of the sphere it starts
@@ -883,6 +883,9 @@ __device__ __forceinline__ void closestHitGrid(const TraceParams &P, double sx, 
 // of closestHitScreened; lanes of a wave follow different lists, the instructions are shared.  A sphere that is on
 // no list of a ray has a provably negative discriminant in the reference (or can only be met beyond the light, which
 // lighting() treats like no hit, mainTracing.c:211-215), so hit masks, hit points and colours are unchanged.
+// GLOBAL (level 7: scenes with mirrors, whose other rays walk the uniform grid, and scenes whose tables do not fit in
+// LDS): the camera table, the occluder lists and the exact doubles are read from global memory; the spheres' screen
+// table and the waves' tile lists are in LDS as at level 6.
 
 // The cone that bounds every primary ray of a tile, as (axis t, cos, sin of the half-angle tau), and whether an entry
 // (a, kappa2) of a cone table can be met by a line inside it.  The table's kappa2 = cos^2(A) - 16 u rounded down
@@ -905,6 +908,7 @@ __device__ __forceinline__ bool coneMeetsTile(const float4v e, float sinA, const
 // The wave's tile list: sphere numbers (16 bits) at `list` in LDS; returns the count, or -1 when the list would
 // exceed kTileListCap entries or the tile has no usable bounding cone (the caller then lists every sphere).  Called by
 // all 64 lanes.  (xLo, xHi) x (yLo, yHi): world offsets on the screen plane that bound every sample of the tile.
+template <bool GLOBAL>
 __device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles C, double xLo, double xHi, double yLo,
                                              double yHi, unsigned short *list) {
     const int lane = lane64();
@@ -935,10 +939,11 @@ __device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles 
     if (!T.ok) return -1;
 
     // (group entries first, member entries behind them, in both tables)
-    const float4v *groups = (const float4v *)((const char *)ldsGeom + P.listGroupsOff);
+    const char *image = GLOBAL ? (const char *)P.geomF : (const char *)ldsGeom;
+    const float4v *groups = (const float4v *)(image + P.listGroupsOff);
     const float4v *members = groups + P.listGroups;
-    const float *groupSin = (const float *)((const char *)ldsGeom + P.listSinesOff), *memberSin = groupSin + P.listGroups;
-    const unsigned short *shapeOf = (const unsigned short *)((const char *)ldsGeom + P.listShapeOff);
+    const float *groupSin = (const float *)(image + P.listSinesOff), *memberSin = groupSin + P.listGroups;
+    const unsigned short *shapeOf = (const unsigned short *)(image + P.listShapeOff);
     const int gs = P.groupSize;
     int count = 0;
     for (int g0 = 0; g0 < P.listGroups; g0 += 64) {
@@ -964,19 +969,22 @@ __device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles 
     return count <= kTileListCap ? count : -1;
 }
 
-// Closest hit among the spheres of the lane's list: `len` sphere numbers from chunk `pos` of the pool on (LDS; a
-// chunk is four 16-bit numbers, fetched with one read and used up over four trips).  One candidate is
+// Closest hit among the spheres of the lane's list: `len` sphere numbers from chunk `pos` on (a chunk is four 16-bit
+// numbers, fetched with one read and used up over four trips) -- of the list pool, or, `tile`, of LDS, where the
+// waves' tile lists are (at level 6 the pool is in LDS too and `pos` counts from its start either way).  One candidate is
 // parked per lane and the exact test runs, for every lane that has one parked, when some lane needs the slot again
 // or has reached the end of its list -- one code site, shared by lanes whose lists differ.  Spheres are met out of
 // index order: see closestHitGrouped for why the winner does not depend on it.
 // `self` >= 0: the sphere a shadow ray starts on, which its list leaves out.  The ray starts a hair outside it; when
 // it moves away from the centre (the light lies in front of the surface) both roots are negative and the sphere is
 // done with (the first clause of exactSphereLazy: shapes.c:62-66 reports a miss); otherwise it is the first candidate.
+template <bool GLOBAL>
 __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx, double sy, double sz, double dx, double dy,
-                                                double dz, int pos, int len, int self, float negThreshold, Hit &h) {
+                                                double dz, int pos, int len, bool tile, int self, float negThreshold, Hit &h) {
     const float4v *aos = (const float4v *)ldsGeom;
-    const double4v *geom = (const double4v *)((const char *)ldsGeom + P.exactLdsOffset);
-    const unsigned long long *pool = (const unsigned long long *)((const char *)ldsGeom + P.listPoolOff);
+    const double4v *geom = GLOBAL ? (const double4v *)P.geom : (const double4v *)((const char *)ldsGeom + P.exactLdsOffset);
+    const unsigned long long *pool = (const unsigned long long *)((GLOBAL ? (const char *)P.geomF : (const char *)ldsGeom) + P.listPoolOff);
+    const unsigned long long *tiles = (const unsigned long long *)ldsGeom;
     unsigned long long chunk = 0;
     int trip = 0;
     Best closest = {0, -1, -1};
@@ -996,7 +1004,10 @@ __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx,
     }
     while (__ballot(len > 0 || pending >= 0)) {
         int j = -1;
-        if ((trip & 3) == 0 && len > 0) chunk = pool[pos++];  // (the trip count is the same for all lanes)
+        if ((trip & 3) == 0 && len > 0) {  // (the trip count is the same for all lanes)
+            chunk = GLOBAL && tile ? tiles[pos] : pool[pos];
+            ++pos;
+        }
         ++trip;
         if (len > 0) {
             const int k = (int)(chunk & 0xffffu);

@@ -54,7 +54,10 @@ namespace {
 // 4 = large scenes: three-level screens per ray family (an entry per 8 groups on top), the cone families' member
 //     sections left in global memory;
 // 5 = level 4 with a uniform grid walked lane by lane in place of the ball family (closestHitGrid);
-// 6 = candidate lists: per tile for primary rays, per (sphere, light) for shadow rays (closestHitLists).
+// 6 = candidate lists: per tile for primary rays, per (sphere, light) for shadow rays (closestHitLists), everything in
+//     LDS; scenes without mirrors;
+// 7 = candidate lists kept in global memory (spheres' screen table and tile lists in LDS), and closestHitGrid for the
+//     rays behind a mirror.
 // LDSGEOM: the table the hot loop reads (screen table, or the doubles when SCREEN == 0) is staged in LDS.
 // EXACTLDS (SCREEN > 0 only): the exact doubles are staged in LDS as well, behind the screen table; otherwise the
 // rare exact tests read them from global memory.
@@ -68,8 +71,13 @@ namespace {
 template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS, bool MIRRORS = true>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
     static_assert(MIRRORS || !TRANSP, "the tree walk needs the stack");
+    constexpr bool LISTS = SCREEN == 6 || SCREEN == 7;   // candidate lists
+    constexpr bool GLOBALLISTS = SCREEN == 7;             // ... read from global memory
     if (LDSGEOM) {
-        if (SCREEN == 4 || SCREEN == 5) {
+        if (LISTS) {
+            float *dst = (float *)ldsGeom;
+            for (int i = threadIdx.x; i < P.ldsHeadFloats; i += blockDim.x) dst[i] = P.geomF[i];
+        } else if (SCREEN == 4 || SCREEN == 5) {
             float *dst = (float *)ldsGeom;
             for (int i = threadIdx.x; i < P.ldsHeadFloats; i += blockDim.x) dst[i] = P.geomF[i];
             float *tail = dst + 4 * (size_t)P.ballMembersLds;
@@ -101,9 +109,10 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     const unsigned long long stampBegin = clock64();
 #endif
 
-    // SCREEN == 6: where the wave's tile list starts in the list pool (in LDS, one list per wave of the workgroup; in
-    // chunks of four entries) and how long the current tile's is (kListAll: every sphere)
-    const int tileListPos = SCREEN == 6 ? ((P.listTileOff - P.listPoolOff) >> 3) + (int)(threadIdx.x >> 6) * (kTileListCap / 4) : 0;
+    // Candidate lists: where the wave's tile list starts (in LDS, one list per wave of the workgroup; in chunks of four
+    // entries, counted from the pool's start at level 6 and from the start of LDS at level 7) and how long the current
+    // tile's is (kListAll: every sphere)
+    const int tileListPos = !LISTS ? 0 : ((GLOBALLISTS ? P.listTileOff : P.listTileOff - P.listPoolOff) >> 3) + (int)(threadIdx.x >> 6) * (kTileListCap / 4);
     int tileListLen = 0;
 
     // rayIntersectAvoid for one ray per lane (mainTracing.c:128-153): picks the walk the job was built for; returns
@@ -118,44 +127,57 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             if (AVOID == 1) avoidShape = L.avoidFirst;
             if (AVOID == 2 && L.avoidNum > 0) avoidRow = P.avoidMask + (size_t)li * P.numShapes;
         }
-        if (SCREEN == 6 && AVOID == 0) {
+        if (SCREEN == 7 && mode != M_SHADOW && depth > 0) {
+            // a ray that left a mirror passes through no point known ahead of time: the uniform grid
+            const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
+            if (s1 < P.familyScale) {
+                const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
+                closestHitGrid<AVOID>(P, o[0], o[1], o[2], d[0], d[1], d[2], -1, nullptr, negThreshold, INFINITY, h);
+            } else {
+                closestHit<AVOID, false>(P, o[0], o[1], o[2], d[0], d[1], d[2], -1, nullptr, h);
+            }
+        } else if (LISTS && AVOID == 0) {
             // Level 6 in a scene whose lights avoid nothing: one walk for every ray.  A ray that starts beyond the
             // scale the lists were built for (none does in a job that qualifies) looks at every sphere, behind the
             // single-precision screen alone, whose threshold never proves anything for coordinates it cannot bound.
             const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
             const float negThreshold = s1 < 1e15 ? -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001) : -INFINITY;
             int pos = tileListPos, len = tileListLen, self = -1;
+            bool tile = true;
             if (mode == M_SHADOW) {
-                const unsigned *index = (const unsigned *)((const char *)ldsGeom + P.listIndexOff);
+                const unsigned *index = (const unsigned *)((GLOBALLISTS ? (const char *)P.geomF : (const char *)ldsGeom) + P.listIndexOff);
                 const unsigned w = index[from * P.numLights + li];
                 pos = (int)(w & 0xfffffu);
                 len = (int)(w >> 20);
                 self = from;
+                tile = false;
             }
-            if (len == (int)kListAll || !(s1 < P.familyScale)) { pos = 0; len = P.numSpheres; self = -1; }  // (the pool starts with every sphere)
-            closestHitLists(P, o[0], o[1], o[2], d[0], d[1], d[2], pos, len, self, negThreshold, h);
+            if (len == (int)kListAll || !(s1 < P.familyScale)) { pos = 0; len = P.numSpheres; self = -1; tile = false; }  // (the pool starts with every sphere)
+            closestHitLists<GLOBALLISTS>(P, o[0], o[1], o[2], d[0], d[1], d[2], pos, len, tile, self, negThreshold, h);
         } else if (SCREEN) {
             const double s1 = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
             // (level 6: every direction comes out of vecUnit -- unit length or the zero vector -- and every origin is a
             // screen point or a point of a sphere, all finite in a job that qualifies; the test on the origin stays)
-            const bool tame = SCREEN == 6 || (s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001);
+            const bool tame = LISTS || (s1 < 1e15 && fabs(d[0]) <= 1.0000001 && fabs(d[1]) <= 1.0000001 && fabs(d[2]) <= 1.0000001);
             if (tame && (SCREEN == 1 || s1 < (SCREEN >= 3 ? P.familyScale : 1e5))) {
                 const float negThreshold = -(float)((64.0 * 5.9604644775390625e-08 * s1 * s1 + 1e-30) * 1.000001);
-                if (SCREEN == 6) {
+                if (LISTS) {
                     // the lane's list: the occluders of (sphere the ray starts on, light), or what the tile can see
                     // (a shadow ray's own sphere is not on its list: closestHitLists looks at it first)
                     int pos = tileListPos, len = tileListLen, self = -1;
+                    bool tile = true;
                     if (mode == M_SHADOW) {
-                        const unsigned *index = (const unsigned *)((const char *)ldsGeom + P.listIndexOff);
+                        const unsigned *index = (const unsigned *)((GLOBALLISTS ? (const char *)P.geomF : (const char *)ldsGeom) + P.listIndexOff);
                         const unsigned w = index[from * P.numLights + li];
                         pos = (int)(w & 0xfffffu);
                         len = (int)(w >> 20);
                         self = from;
+                        tile = false;
                         if (AVOID == 1 && from == avoidShape) self = -1;
                         if (AVOID == 2 && avoidRow && avoidRow[from]) self = -1;
                     }
-                    if (len == (int)kListAll) { pos = 0; len = P.numSpheres; self = -1; }  // (the pool starts with every sphere)
-                    closestHitLists(P, o[0], o[1], o[2], d[0], d[1], d[2], pos, len, self, negThreshold, h);
+                    if (len == (int)kListAll) { pos = 0; len = P.numSpheres; self = -1; tile = false; }  // (the pool starts with every sphere)
+                    closestHitLists<GLOBALLISTS>(P, o[0], o[1], o[2], d[0], d[1], d[2], pos, len, tile, self, negThreshold, h);
                 } else if (SCREEN >= 3) {
                     // which fixed point the ray's line passes through decides the table it is screened with
                     int family = P.ballFamily;
@@ -235,13 +257,13 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         const bool inside = ix < P.nCols && by < P.bandRows;
 
         const ConstDoubles cam = cameraView(P);
-        if (SCREEN == 6) {  // what this tile's primary rays can see, worked out once by all lanes together
+        if (LISTS) {  // what this tile's primary rays can see, worked out once by all lanes together
             const int ix0 = tx * kTile, ix1 = min(ix0 + kTile, P.nCols) - 1;
             const int iy0 = P.row0 + ty * kTile, iy1 = P.row0 + min(ty * kTile + kTile, P.bandRows) - 1;
             // samples lie at the pixel's offsets plus 0 (the mask ray) .. numPasses sub-steps (mainTracing.c:405-406)
             const double spanX = P.aliasing ? cam[CAM_SUBX] * (double)P.numPasses : 0.0;
             const double spanY = P.aliasing ? cam[CAM_SUBY] * (double)P.numPasses : 0.0;
-            const int found = buildTileList(P, cam, P.colOff[ix0] + fmin(spanX, 0.0), P.colOff[ix1] + fmax(spanX, 0.0),
+            const int found = buildTileList<GLOBALLISTS>(P, cam, P.colOff[ix0] + fmin(spanX, 0.0), P.colOff[ix1] + fmax(spanX, 0.0),
                                             P.rowOff[iy0] + fmin(spanY, 0.0), P.rowOff[iy1] + fmax(spanY, 0.0),
                                             (unsigned short *)((char *)ldsGeom + P.listTileOff) + (threadIdx.x >> 6) * kTileListCap);
             tileListLen = found < 0 ? (int)kListAll : found;
@@ -285,7 +307,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 if (P.aliasing) {
                     // k = s / numPasses by a multiplication (exact below 2^20 samples, host_job.h)
                     const int k = (int)__umulhi((unsigned)s, P.numPassesRecip), l = s - k * P.numPasses;
-                    if (SCREEN == 6 && GRAFT_SAMPLE_TABLE && !MANYCURSORS && P.sampleTableOff >= 0) {  // the two steps' scale factors from the tile's table
+                    if (LISTS && GRAFT_SAMPLE_TABLE && !MANYCURSORS && P.sampleTableOff >= 0) {  // the two steps' scale factors from the tile's table
                         const double *tab = (const double *)((const char *)ldsGeom + P.sampleTableOff) + (threadIdx.x >> 6) * 16 * P.numPasses;
                         const double scaleX = tab[lx * P.numPasses + k], scaleY = tab[(kTile + ly) * P.numPasses + l];
                         for (int c = 0; c < 3; ++c) {
@@ -339,7 +361,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             // maxDepth <= 0: shootRay returns black before it looks at the scene (mainTracing.c:302-306), for every
             // sample; with anti-aliasing the background-seeded sum (:395) takes n additions of zero
             const bool traceNothing = P.maxDepth <= 0;
-            if (SCREEN == 6 && tileListLen == 0 && !traceNothing) {
+            if (LISTS && tileListLen == 0 && !traceNothing) {
                 // No sphere can be met by any primary ray of this tile (mask ray included): every sample is the
                 // background colour (mainTracing.c:314-317), summed as the reference sums it (:419).  The queries
                 // count as answered.
@@ -417,7 +439,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                                           : (EXACTLDS || SCREEN == 6) ? (const double *)((const char *)ldsGeom + P.exactLdsOffset) : P.geom;
                         if (h.kind == GRAFT_SPHERE) {  // shapes.c:69-71
                             const double *c = g + 4 * (size_t)h.slot;
-                            if (SCREEN == 6 && GRAFT_SHARED_RCP) unit3Shared(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
+                            if (LISTS && GRAFT_SHARED_RCP) unit3Shared(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
                             else unit3(loc[0] - c[0], loc[1] - c[1], loc[2] - c[2], nrm[0], nrm[1], nrm[2]);
                         } else {  // shapes.c:91
                             const double *pn = g + 4 * (size_t)P.numSpheres + 6 * (size_t)h.slot + 3;
@@ -652,7 +674,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         rayReflects = 1;  // launchRays passes shouldReflect = 1, mainTracing.c:391
                         mode = M_RADIANCE;
                     }
-                    if (SCREEN == 6 && GRAFT_SHARED_RCP) unit3Shared(vx, vy, vz, d[0], d[1], d[2]);
+                    if (LISTS && GRAFT_SHARED_RCP) unit3Shared(vx, vy, vz, d[0], d[1], d[2]);
                     else unit3(vx, vy, vz, d[0], d[1], d[2]);
                     if (next != NEXT_SAMPLE) {  // vecNudge, mainTracing.c:163-167
                         o[0] = loc[0] + .000001 * d[0];
@@ -840,6 +862,7 @@ template <int A, bool M>
 TraceFn pickKernelA(bool lds, int screen, bool exactLds, bool mirrors) {
 #ifdef GRAFT_DEV_KERNELS
     if (A != 0 || !lds) return nullptr;
+    if (screen == 7) return mirrors ? traceKernel<0, true, 7, false, false, M, true> : traceKernel<0, true, 7, false, false, M, false>;
     if (screen == 6) return traceKernel<0, true, 6, false, false, M, false>;
     if (screen == 5) return traceKernel<0, true, 5, false, false, M>;
     if (screen == 3 && exactLds) return mirrors ? traceKernel<0, true, 3, true, false, M> : traceKernel<0, true, 3, true, false, M, false>;
@@ -854,7 +877,8 @@ TraceFn pickKernelA(bool lds, int screen, bool exactLds, bool mirrors) {
     if (screen == 3) return exactLds ? traceKernel<A, true, 3, true, false, M, false> : traceKernel<A, true, 3, false, false, M, false>;
     if (screen == 4) return traceKernel<A, true, 4, false, false, M>;
     if (screen == 5) return traceKernel<A, true, 5, false, false, M>;
-    return traceKernel<A, true, 6, false, false, M, false>;  // (packJob gives level 6 to scenes without mirrors only)
+    if (screen == 6) return traceKernel<A, true, 6, false, false, M, false>;  // (packJob gives level 6 to scenes without mirrors only)
+    return mirrors ? traceKernel<A, true, 7, false, false, M, true> : traceKernel<A, true, 7, false, false, M, false>;
 #endif
 }
 

@@ -152,13 +152,17 @@ inline bool packLevel5(TableCache &cache, const std::vector<double> &sph, size_t
     return true;
 }
 
-// Level 6 (closestHitLists): every primary ray looks only at the spheres its TILE can see (a list the wave builds per
-// tile from the camera's two-level cone table), every shadow ray only at the spheres that can lie between the sphere
-// it starts on and its light (lists built here, per light).  Builds the LDS image described at TraceParams::listGroups
-// and sets the launch parameters; returns false when the job does not qualify or the image does not fit.
-inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const GraftView *view,
-                       const std::vector<DevLight> &lights, const std::vector<unsigned char> &mask, int nS, double scale,
-                       std::vector<float> &image, TraceParams &P, size_t &ldsBytes, int &block) {
+// Levels 6 and 7 (closestHitLists): every primary ray looks only at the spheres its TILE can see (a list the wave builds
+// per tile from the camera's two-level cone table), every shadow ray only at the spheres that can lie between the
+// sphere it starts on and its light (lists built here, per light).  Builds the image described at
+// TraceParams::listGroups and sets the launch parameters; returns false when the job does not qualify or the image
+// does not fit.  `inLds`: the whole image is staged in LDS, exact doubles included (level 6); otherwise only the
+// spheres' screen table and -- `wantGrid`: the scene has mirrors, whose rays walk it -- the uniform grid are, and the
+// lists and the camera table stay in global memory behind them (level 7).  `staged` = bytes of the image that go to LDS.
+inline bool packLists(TableCache &cache, const std::vector<double> &sph, const GraftView *view,
+                      const std::vector<DevLight> &lights, const std::vector<unsigned char> &mask, int nS, double scale,
+                      bool inLds, bool wantGrid, std::vector<float> &image, TraceParams &P, size_t &staged,
+                      size_t &ldsBytes, int &block) {
     const size_t n = sph.size() / 4, nL = lights.size();
     if (n > 65535 || n * nL > (1u << 22)) return false;
     // the tile's bounding cone is drawn around the rays of its first and last columns and rows
@@ -166,6 +170,15 @@ inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const 
         if (!(view->colOffsets[i] >= view->colOffsets[i - 1])) return false;
     for (int i = 1; i < view->nRows; ++i)
         if (!(view->rowOffsets[i] >= view->rowOffsets[i - 1])) return false;
+    if (wantGrid) {
+        if (!cache.haveGrid) {
+            cache.gridOk = packGrid(sph, cache.grid);
+            cache.haveGrid = true;
+            cache.builds++;
+        }
+        if (!cache.gridOk) return false;
+    }
+    const GridTable &grid = cache.grid;
     const TwoLevelTable &cam = cache.cone(view->camPos, scale);
     const size_t gs = (size_t)cam.kGroup, G = cam.memberShape.size() / gs;
     std::vector<const LightLists *> lists;
@@ -177,14 +190,18 @@ inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const 
     }
     auto up = [](size_t x, size_t a) { return (x + a - 1) / a * a; };
     const size_t entries = G + G * gs;  // group entries, then member entries
-    const size_t oAos = 0, oExact = up(oAos + 16 * n, 32), oGroups = up(oExact + 32 * n, 16), oSines = oGroups + 16 * entries,
-                 oShape = oSines + 4 * entries, oIndex = up(oShape + 2 * G * gs, 4), oPool = up(oIndex + 4 * n * nL, 8);
+    const size_t oAos = 0, oExact = up(oAos + 16 * n, 32), afterExact = inLds ? oExact + 32 * n : oAos + 16 * n;
+    const size_t oCells = up(afterExact, 16), oRefs = oCells + (wantGrid ? 4 * grid.cells.size() : 0);
+    const size_t afterGrid = up(oRefs + (wantGrid ? 2 * grid.refs.size() : 0), 16);
+    const size_t oGroups = afterGrid, oSines = oGroups + 16 * entries, oShape = oSines + 4 * entries,
+                 oIndex = up(oShape + 2 * G * gs, 4), oPool = up(oIndex + 4 * n * nL, 8);
     size_t poolEntries = up(n, 4);  // the list of all spheres comes first; every list starts at a multiple of 4 entries
     std::vector<size_t> base(nL);
     for (size_t i = 0; i < nL; ++i) { base[i] = poolEntries; poolEntries += lists[i]->pool.size(); }
     if (poolEntries / 4 >= (1u << 20)) return false;
     const size_t blob = up(oPool + 2 * poolEntries, 16);
-    // behind the image: a tile list per wave and, where it fits, the waves' tables of sample scale factors
+    staged = inLds ? blob : afterGrid;
+    // in LDS behind the staged part: a tile list per wave and, where it fits, the waves' tables of sample scale factors
     // (launches of fewer than four samples per pixel run kernels that do not look at the table: launchTrace)
     const bool wantSamples = view->aliasing && view->numPasses >= 2 && view->numPasses <= kSampleTablePasses;
     const size_t perWave = 2 * kTileListCap, perWaveSamples = 8 * 16 * (size_t)(wantSamples ? view->numPasses : 0);
@@ -193,23 +210,27 @@ inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const 
     for (int withSamples = wantSamples ? 1 : 0; withSamples >= 0 && !block; --withSamples)
         for (int b = kSmallBlock; b <= kLargeBlock; b *= 2) {
             const size_t waves = (size_t)(b / 64);
-            const size_t total = blob + waves * perWave + (withSamples ? waves * perWaveSamples : 0);
+            const size_t total = staged + waves * perWave + (withSamples ? waves * perWaveSamples : 0);
             const size_t limit = b == kSmallBlock ? kLdsSmall : b == 2 * kSmallBlock ? 2 * kLdsSmall : kLdsMax;
             if (total <= limit) {
                 block = b;
                 ldsBytes = total;
-                if (withSamples) P.sampleTableOff = (int)(blob + waves * perWave);
+                if (withSamples) P.sampleTableOff = (int)(staged + waves * perWave);
                 break;
             }
         }
     if (!block) return false;
-    std::vector<unsigned char> lds(blob, 0);
+    std::vector<unsigned char> img(blob, 0);
     for (size_t k = 0; k < n; ++k) {
         float e[4] = {(float)sph[4 * k], (float)sph[4 * k + 1], (float)sph[4 * k + 2], 0.0f};
         if (!screenRho(&sph[4 * k], sph[4 * k + 3], e[3])) return false;
-        memcpy(&lds[oAos + 16 * k], e, sizeof e);
+        memcpy(&img[oAos + 16 * k], e, sizeof e);
     }
-    memcpy(&lds[oExact], sph.data(), 32 * n);
+    if (inLds) memcpy(&img[oExact], sph.data(), 32 * n);
+    if (wantGrid) {
+        memcpy(&img[oCells], grid.cells.data(), 4 * grid.cells.size());
+        memcpy(&img[oRefs], grid.refs.data(), 2 * grid.refs.size());
+    }
     // cone entries as {axis, cos A'} and sin A', from the table's -kappa2 = -(cos^2 A'): the cosine rounded down, the
     // sine up (either way the cone only widens); an entry that always passes gets cos = -2, one that never does +inf
     auto coneEntries = [&](size_t first, size_t count, size_t at) {
@@ -225,34 +246,38 @@ inline bool packLevel6(TableCache &cache, const std::vector<double> &sph, const 
                 sn = -floatBelow(-sqrt(1.0 - (double)c * (double)c) * (1.0 + 1e-12));
             }
             plain[4 * e + 3] = c;
-            memcpy(&lds[oGroups + 16 * (at + e)], &plain[4 * e], 16);
-            memcpy(&lds[oSines + 4 * (at + e)], &sn, 4);
+            memcpy(&img[oGroups + 16 * (at + e)], &plain[4 * e], 16);
+            memcpy(&img[oSines + 4 * (at + e)], &sn, 4);
         }
     };
     coneEntries(0, G, 0);
     coneEntries((size_t)cam.memberBase, G * gs, G);
     for (size_t m = 0; m < G * gs; ++m) {
         const unsigned short id = cam.memberShape[m] < 0 ? (unsigned short)0xffff : (unsigned short)cam.memberShape[m];
-        memcpy(&lds[oShape + 2 * m], &id, 2);
+        memcpy(&img[oShape + 2 * m], &id, 2);
     }
     for (size_t k = 0; k < n; ++k)
         for (size_t i = 0; i < nL; ++i) {
             unsigned w = lists[i]->index[k];
             if ((w >> 20) != kListAll) w += (unsigned)(base[i] / 4);  // (chunk numbers stay below 2^20: checked above)
-            memcpy(&lds[oIndex + 4 * (k * nL + i)], &w, 4);
+            memcpy(&img[oIndex + 4 * (k * nL + i)], &w, 4);
         }
     for (size_t k = 0; k < n; ++k) {
         const unsigned short id = (unsigned short)k;
-        memcpy(&lds[oPool + 2 * k], &id, 2);
+        memcpy(&img[oPool + 2 * k], &id, 2);
     }
     for (size_t i = 0; i < nL; ++i)
-        if (!lists[i]->pool.empty()) memcpy(&lds[oPool + 2 * base[i]], lists[i]->pool.data(), 2 * lists[i]->pool.size());
+        if (!lists[i]->pool.empty()) memcpy(&img[oPool + 2 * base[i]], lists[i]->pool.data(), 2 * lists[i]->pool.size());
     image.assign(blob / 4, 0.0f);
-    memcpy(image.data(), lds.data(), blob);
+    memcpy(image.data(), img.data(), blob);
     P.exactLdsOffset = (int)oExact;
     P.listGroups = (int)G;
     P.listGroupsOff = (int)oGroups; P.listSinesOff = (int)oSines; P.listShapeOff = (int)oShape;
-    P.listIndexOff = (int)oIndex; P.listPoolOff = (int)oPool; P.listTileOff = (int)blob;
+    P.listIndexOff = (int)oIndex; P.listPoolOff = (int)oPool; P.listTileOff = (int)staged;
+    if (wantGrid) {
+        P.gridNx = grid.n[0]; P.gridNy = grid.n[1]; P.gridNz = grid.n[2];
+        P.gridCellsOff = (int)oCells; P.gridRefsOff = (int)oRefs; P.gridAosOff = (int)oAos;
+    }
     return true;
 }
 
@@ -400,8 +425,50 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     if (set.groupSize >= 4 && set.groupSize <= 64 && set.groupSize % 4 == 0) groupSize = set.groupSize;
     P.groupSize = groupSize;
     const bool wantGroups = screen && screenCap >= 2 && pln.empty() && !transparent;
+    // the apexes of the ray families: the camera (perspective only), then every light
+    std::vector<std::array<double, 3>> apexes;
+    if (view->projectionType == GRAFT_PERSPECTIVE) apexes.push_back({view->camPos[0], view->camPos[1], view->camPos[2]});
+    const int lightBase = (int)apexes.size();
+    for (int i = 0; i < nL; ++i) apexes.push_back({lights[i].loc[0], lights[i].loc[1], lights[i].loc[2]});
+    // scale: the largest |.|_1 of anything a screened ray can start from or aim at, rounded up to a power of two
+    // (any larger value is valid: it only widens the margins) so that zooming or turning the view leaves the
+    // lights' tables reusable
+    double scale = 0;
+    {
+        const double offs = fabs(view->subStepX) * (view->numPasses + 1) + fabs(view->subStepY) * (view->numPasses + 1);
+        double colMax = 0, rowMax = 0;
+        for (int i = 0; i < view->nCols; ++i) colMax = fmax(colMax, fabs(view->colOffsets[i]));
+        for (int i = 0; i < view->nRows; ++i) rowMax = fmax(rowMax, fabs(view->rowOffsets[i]));
+        scale = fabs(view->screenCenter[0]) + fabs(view->screenCenter[1]) + fabs(view->screenCenter[2]) + 2 * (colMax + rowMax + offs);
+        for (size_t k = 0; k < sph.size() / 4; ++k)
+            scale = fmax(scale, fabs(sph[4 * k]) + fabs(sph[4 * k + 1]) + fabs(sph[4 * k + 2]) + sqrt(sph[4 * k + 3]));
+        for (const auto &a : apexes) scale = fmax(scale, fabs(a[0]) + fabs(a[1]) + fabs(a[2]));
+        if (scale > 0 && scale < kGroupScale) scale = fmax(1.0, exp2(ceil(log2(scale))));  // (NaN stays NaN)
+    }
+    // Candidate lists first: they need neither the ball table nor the lights' cone tables.  Level 6: everything in LDS
+    // (scenes without mirrors that fit); level 7: lists in global memory, and a grid in LDS for the rays behind a mirror.
+    bool spheresInRange = sph.size() / 4 >= 64;
+    for (size_t k = 0; k < sph.size() / 4 && spheresInRange; ++k)  // (what packBallTable asks of a scene; rejects NaN)
+        spheresInRange = fabs(sph[4 * k]) + fabs(sph[4 * k + 1]) + fabs(sph[4 * k + 2]) + sqrt(sph[4 * k + 3]) < kGroupScale;
+    if (wantGroups && screenCap >= 6 && nL <= 7 && lightBase == 1 && scale < kGroupScale && spheresInRange) {
+        if (cache.groupSize != groupSize || cache.sph != sph) cache.reset(sph, groupSize);
+        cache.makeRoom(apexes.size());
+        std::vector<float> image;
+        size_t staged = 0, ldsBytes = 0;
+        int block = 0, got = 0;
+        if (!mirrors && packLists(cache, sph, view, lights, mask, nS, scale, true, false, image, P, staged, ldsBytes, block)) got = 6;
+        else if (screenCap >= 7 && packLists(cache, sph, view, lights, mask, nS, scale, false, mirrors, image, P, staged, ldsBytes, block)) got = 7;
+        if (got) {
+            screen = got;
+            tableF.swap(image);
+            P.familyScale = scale;
+            P.ldsHeadFloats = (int)(staged / 4);
+            J.ldsBytes = ldsBytes;
+            J.block = block;
+        }
+    }
     const TwoLevelTable *balls = nullptr;
-    if (wantGroups) {
+    if (wantGroups && screen < 6) {
         if (cache.groupSize != groupSize || cache.sph != sph) cache.reset(sph, groupSize);
         if (!cache.haveBalls) {
             cache.ballsOk = packBallTable(sph, groupSize, cache.balls);
@@ -419,37 +486,7 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     }
     // per-family tables: cones seen from the camera (perspective only) and from every light, then the ball table
     if (screen == 2 && screenCap >= 3 && nL <= 7) {
-        std::vector<std::array<double, 3>> apexes;
-        if (view->projectionType == GRAFT_PERSPECTIVE) apexes.push_back({view->camPos[0], view->camPos[1], view->camPos[2]});
-        const int lightBase = (int)apexes.size();
-        for (int i = 0; i < nL; ++i) apexes.push_back({lights[i].loc[0], lights[i].loc[1], lights[i].loc[2]});
-        // scale: the largest |.|_1 of anything a screened ray can start from or aim at, rounded up to a power of two
-        // (any larger value is valid: it only widens the margins) so that zooming or turning the view leaves the
-        // lights' tables reusable
-        double scale = 0, offs = fabs(view->subStepX) * (view->numPasses + 1) + fabs(view->subStepY) * (view->numPasses + 1);
-        double colMax = 0, rowMax = 0;
-        for (int i = 0; i < view->nCols; ++i) colMax = fmax(colMax, fabs(view->colOffsets[i]));
-        for (int i = 0; i < view->nRows; ++i) rowMax = fmax(rowMax, fabs(view->rowOffsets[i]));
-        scale = fabs(view->screenCenter[0]) + fabs(view->screenCenter[1]) + fabs(view->screenCenter[2]) + 2 * (colMax + rowMax + offs);
-        for (size_t k = 0; k < sph.size() / 4; ++k)
-            scale = fmax(scale, fabs(sph[4 * k]) + fabs(sph[4 * k + 1]) + fabs(sph[4 * k + 2]) + sqrt(sph[4 * k + 3]));
-        for (const auto &a : apexes) scale = fmax(scale, fabs(a[0]) + fabs(a[1]) + fabs(a[2]));
-        if (scale > 0 && scale < kGroupScale) scale = fmax(1.0, exp2(ceil(log2(scale))));  // (NaN stays NaN)
-        size_t ldsBytes6 = 0;
-        int block6 = 0;
-        if (screenCap >= 6 && lightBase == 1 && scale < kGroupScale && !mirrors) {
-            cache.makeRoom(apexes.size());
-            std::vector<float> image6;
-            if (packLevel6(cache, sph, view, lights, mask, nS, scale, image6, P, ldsBytes6, block6)) {
-                screen = 6;
-                tableF.swap(image6);
-                memberShape.clear();
-                P.familyScale = scale;
-                J.ldsBytes = ldsBytes6;
-                J.block = block6;
-            }
-        }
-        if (screen != 6 && !apexes.empty() && scale < kGroupScale) {  // (NaN fails the comparison)
+        if (!apexes.empty() && scale < kGroupScale) {  // (NaN fails the comparison)
             std::vector<const TwoLevelTable *> fam;
             cache.makeRoom(apexes.size());
             for (size_t f = 0; f < apexes.size(); ++f) fam.push_back(&cache.cone(apexes[f].data(), scale));
@@ -544,7 +581,7 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     memcpy(&host[J.oCol], view->colOffsets, sizeof(double) * view->nCols);
     memcpy(&host[J.oRow], view->rowOffsets, sizeof(double) * view->nRows);
     memcpy(&host[J.oCam], &cam, sizeof cam);
-    if (screen == 5) {
+    if (screen == 5 || (screen == 7 && mirrors)) {
         DevGrid g;
         for (int a = 0; a < 3; ++a) { g.lo[a] = cache.grid.lo[a]; g.hi[a] = cache.grid.hi[a]; g.cs[a] = cache.grid.cs[a]; g.invCs[a] = cache.grid.invCs[a]; }
         memcpy(&host[J.oGrid], &g, sizeof g);
@@ -557,7 +594,7 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
                             : screen ? sizeof(float) * tableF.size() : sizeof(double) * (size_t)(P.geomDoubles + kGeomPad);
     const size_t exactBytes = sizeof(double) * (size_t)P.geomDoubles;
     J.transp = transparent;
-    if (screen == 6) {  // (LDS image, workgroup size and the offset of the exact doubles: packLevel6)
+    if (screen >= 6) {  // (LDS image, workgroup size and the offset of the exact doubles: packLists)
         J.lds = true;
         J.exactLds = false;
         return GRAFT_OK;

@@ -78,7 +78,7 @@ def device_count():
 
 
 def set_diagnostic(name, value):
-    """graftDiagnosticSet: "screen_cap" 0..6, "group_size" 0|4..64, "tiles_per_ticket", "reserved_cus" (A/B timing,
+    """graftDiagnosticSet: "screen_cap" 0..7, "group_size" 0|4..64, "tiles_per_ticket", "reserved_cus" (A/B timing,
     tests, and room for transfer kernels beside a trace; no setting changes a result).  Returns the previous value."""
     which = _lib.DIAGNOSTICS[name]
     old = lib.graftDiagnosticGet(which)

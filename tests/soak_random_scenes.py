@@ -41,9 +41,9 @@ for seed in range(first, first + count):
         for i, l in enumerate(rt.lights[:rt.numLights]):
             shapes = [rt.shapes[(7 * i + j) % rt.numShapes] for j in range(pick(0, 1, 3))]
             l.avoid, l.avoidNum = shapes, len(shapes)
-    set_diagnostic("screen_cap", pick(0, 1, 2, 3, 5, 6, 6))
+    set_diagnostic("screen_cap", pick(0, 1, 2, 3, 5, 6, 7, 7))
     tp.assert_parity(rt)
     print("seed %d ok: %d shapes, %d lights, depth %d, queries made %d of %d" % (
         seed, rt.numShapes, rt.numLights, rt.maxDepth, rt.last_rays_traced, rt.last_counters[0]), flush=True)
-set_diagnostic("screen_cap", 6)
+set_diagnostic("screen_cap", 7)
 print("soak ok: %d scenes" % count)

@@ -91,9 +91,10 @@ def tangent_radii(s, d, centre, r):
     return out
 
 
-def grazing_scene(offset, fillers, seed, size=(64, 64)):
+def grazing_scene(offset, fillers, seed, size=(64, 64), mirrors=True):
     """A floor sphere, two lights, tangent spheres on the primary rays of a lattice of pixels and on the shadow rays
-    of another lattice, plus `fillers` small random spheres; everything moved by `offset`."""
+    of another lattice, plus `fillers` small random spheres; everything moved by `offset`.  Without `mirrors` no shape
+    reflects (the candidate lists of level 6 take such scenes)."""
     ox, oy, oz = offset
     rt = RayTracer(*size)
     rt.aliasing, rt.numPasses, rt.maxDepth = ANTIALIASING_OFF, 1, 3
@@ -108,7 +109,7 @@ def grazing_scene(offset, fillers, seed, size=(64, 64)):
 
     def add(c, r, refl=0.0):
         nonlocal n
-        rt.sphereSetup(r, c, n, [.3 + .07 * (n % 10), .9 - .06 * (n % 11), .5], refl, 0.1, 1.0, 0.0)
+        rt.sphereSetup(r, c, n, [.3 + .07 * (n % 10), .9 - .06 * (n % 11), .5], refl if mirrors else 0.0, 0.1, 1.0, 0.0)
         n += 1
 
     floor_c, floor_r = [ox, oy - 1180.0, oz + 150.0], 1000.0
@@ -168,8 +169,15 @@ def test_tangent_spheres_ordinary_coordinates(gpu):
     used, want = check_levels(grazing_scene((0.0, 0.0, 0.0), 60, 1), (0, 1, 2, 3))
     assert used == [0, 1, 2, 3]
     assert (want["index"] > 0).sum() > 20   # tangent spheres and fillers are really seen
-    used, _ = check_levels(grazing_scene((0.0, 0.0, 0.0), 2300, 2, size=(48, 48)), (0, 4, 5))
-    assert used == [0, 4, 5]
+    used, _ = check_levels(grazing_scene((0.0, 0.0, 0.0), 2300, 2, size=(48, 48)), (0, 4, 5, 7))
+    assert used == [0, 4, 5, 7]
+    # the candidate lists: tile lists against tangent primary rays, occluder lists against tangent shadow rays
+    used, want = check_levels(grazing_scene((0.0, 0.0, 0.0), 60, 1, mirrors=False), (0, 6))
+    assert used == [0, 6] and (want["index"] > 0).sum() > 20
+    used, _ = check_levels(grazing_scene((0.0, 0.0, 0.0), 60, 1), (0, 7))
+    assert used == [0, 7]
+    used, _ = check_levels(grazing_scene((0.0, 0.0, 0.0), 2300, 2, size=(48, 48), mirrors=False), (0, 7))
+    assert used == [0, 7]
 
 
 def test_tangent_spheres_just_under_the_coordinate_limits(gpu):
@@ -179,11 +187,13 @@ def test_tangent_spheres_just_under_the_coordinate_limits(gpu):
     # rounded-up scale 65536 < 1e5: cone tables at their widest margins; coordinates beyond the grid's limit
     used, _ = check_levels(grazing_scene((1.6e4, 1.5e4, 1.7e4), 60, 4), (0, 2, 3))
     assert used == [0, 2, 3]
+    used, _ = check_levels(grazing_scene((1.6e4, 1.5e4, 1.7e4), 60, 4, mirrors=False), (0, 6))
+    assert used == [0, 6]
     used, _ = check_levels(grazing_scene((1.6e4, 1.5e4, 1.7e4), 2300, 5, size=(48, 48)), (0, 4, 5))
     assert used == [0, 4, 4]
     # just under the grid's limit of 32768
-    used, _ = check_levels(grazing_scene((9.0e3, 9.5e3, 9.0e3), 2300, 6, size=(48, 48)), (0, 4, 5))
-    assert used == [0, 4, 5]
+    used, _ = check_levels(grazing_scene((9.0e3, 9.5e3, 9.0e3), 2300, 6, size=(48, 48)), (0, 4, 5, 7))
+    assert used == [0, 4, 5, 7]
     # negative coordinates
     used, _ = check_levels(grazing_scene((-9.0e3, 8.0e3, -9.5e3), 2300, 7, size=(48, 48)), (0, 5))
     assert used == [0, 5]
@@ -202,4 +212,7 @@ def test_light_and_camera_a_hair_from_a_sphere(gpu, rel):
     r2 = 300.0
     rt.sphereSetup(r2, [cam[0], cam[1], cam[2] + r2 * (1 + rel)], n + 1, [.2, .2, .8], 0.2, 0.1, 1.0, 0.0)
     rt.numShapes = n + 2
-    check_levels(rt, (0, 1, 2, 3))
+    check_levels(rt, (0, 1, 2, 3, 7))
+    for s in rt.shapes[:rt.numShapes]:
+        s.reflectivity = 0.0
+    check_levels(rt, (0, 6))

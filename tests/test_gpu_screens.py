@@ -1,8 +1,9 @@
 """The conservative screens (single-precision per-sphere screen, two-level ball screen, per-family cone screens)
 must never change a result.  Random and adversarial sphere scenes, GPU against the CPU oracle, bit for bit, at
-every screen level (the screen_cap setting, 0..6, caps the level a job may use; 0 is the plain double-precision loop).
-Level 6 (candidate lists) takes scenes without reflecting shapes seen in perspective; the scenes of the other tests
-mostly have mirrors, so the tests at the end of this file run their shapes again without."""
+every screen level (the screen_cap setting, 0..7, caps the level a job may use; 0 is the plain double-precision loop).
+Level 6 (candidate lists in LDS) takes scenes without reflecting shapes seen in perspective; the scenes of the other
+tests mostly have mirrors (level 7: lists in global memory, a grid for the rays behind a mirror), so the tests at the
+end of this file run their shapes again without."""
 import numpy as np
 import pytest
 
@@ -35,7 +36,7 @@ def scene(seed, n, size=(64, 64), lights=3, radius=(5.0, 40.0), box=400.0, refl=
     return rt
 
 
-def check_all_levels(rt, levels=(0, 1, 2, 3, 4, 5, 6)):
+def check_all_levels(rt, levels=(0, 1, 2, 3, 4, 5, 6, 7)):
     want = ob.render(rt, threads=16, want_index=True)
     old = get_diagnostic("screen_cap")
     try:
@@ -118,7 +119,7 @@ def test_nearly_coincident_spheres(gpu):
         rt.sphereSetup(src.unif[3] * (1 + eps), [src.unif[0] + eps * 50, src.unif[1], src.unif[2] * (1 - eps)], n + k,
                        [.2, .9, .2], 0.3, 0.1, 1.0, 0.0)
     rt.numShapes = n + 30
-    check_all_levels(rt, levels=(0, 4, 5))
+    check_all_levels(rt, levels=(0, 4, 5, 7))
 
 
 def test_tiny_giant_and_far_spheres(gpu):
@@ -186,11 +187,14 @@ def large_scene(seed, n, **kw):
 
 
 def test_large_scenes_three_level_walk(gpu):
-    check_all_levels(large_scene(30, 1500, lights=5, refl=0.5, depth=3), levels=(0, 2, 4, 5))
+    check_all_levels(large_scene(30, 1500, lights=5, refl=0.5, depth=3), levels=(0, 2, 4, 5, 7))
     check_all_levels(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7, refl=0.5, depth=3), levels=(0, 4, 5))
     rt = large_scene(32, 2100, lights=4)
     lightSetAvoid(rt.lights[2], [rt.shapes[11]], 1)
-    check_all_levels(rt, levels=(0, 4, 5))
+    check_all_levels(rt, levels=(0, 4, 5, 7))
+    lightSetAvoid(rt.lights[0], [rt.shapes[3], rt.shapes[2101]], 2)   # (2101: the sphere around the camera)
+    check_all_levels(rt, levels=(0, 7))
+    check_all_levels(matte(large_scene(36, 2100, lights=4)), levels=(0, 5, 7))
 
 
 def test_grid_walk_far_from_the_scene(gpu):
@@ -221,7 +225,7 @@ def test_groups_of_sixteen_and_other_sizes(gpu):
 
 def test_levels_are_actually_used(gpu):
     """The scenes above must really reach the screens they are meant to test."""
-    def level(rt, cap=6):
+    def level(rt, cap=7):
         old = set_diagnostic("screen_cap", cap)
         try:
             job = rt.create_job()
@@ -230,13 +234,16 @@ def test_levels_are_actually_used(gpu):
             return lv
         finally:
             set_diagnostic("screen_cap", old)
-    assert level(scene(0, 96)) == 6 and level(scene(0, 96, refl=0.5)) == 3
+    assert level(scene(0, 96)) == 6 and level(scene(0, 96, refl=0.5)) == 7 and level(scene(0, 96, refl=0.5), 6) == 3
     assert [level(scene(0, 96), cap) for cap in (0, 1, 2, 3, 5)] == [0, 1, 2, 3, 3]
     assert level(scenes.workload("cfg4", 64, 64)) == 6 and level(scenes.workload("cfg3", 64, 64)) == 6
     assert level(scenes.workload("cfg4", 64, 64), 5) == 3 and level(scenes.workload("cfg3", 64, 64), 5) == 3
-    assert level(scenes.workload("cfg5", 64, 64)) == 5 and level(scenes.workload("cfg5", 64, 64), 4) == 4
-    assert level(large_scene(30, 1500, lights=5)) == 5 and level(large_scene(30, 1500, lights=5), 3) == 2
-    assert level(matte(large_scene(32, 2100, lights=4))) == 5   # its list tables do not fit in LDS
+    assert level(scenes.workload("cfg5", 64, 64)) == 7 and level(scenes.workload("cfg5", 64, 64), 4) == 4
+    assert level(scenes.workload("cfg5", 64, 64), 6) == 5
+    assert level(large_scene(30, 1500, lights=5)) == 7 and level(large_scene(30, 1500, lights=5), 3) == 2
+    assert level(large_scene(30, 1500, lights=5), 5) == 5
+    assert level(matte(large_scene(32, 2100, lights=4))) == 7   # its list tables do not fit in LDS
+    assert level(matte(large_scene(32, 2100, lights=4)), 6) == 5
     assert level(matte(large_scene(33, 600, lights=3))) == 6
     assert level(scene(11, 130, projection=ORTHOGRAPHIC)) == 3    # no camera to build tile lists around
     assert level(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7)) == 5
