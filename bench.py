@@ -201,6 +201,40 @@ def frame_512(dev):
     return out
 
 
+def host_frame(rt, kernel_ms):
+    """What a host caller pays for the whole frame of the measured workload: graftRenderRows into page-locked host
+    memory (scene and view unchanged since the call before: nothing is packed), per output format.  A large frame is
+    traced in pieces of rows whose copies to the host run beside the tracing of the next pieces; `one_piece` times
+    the same call with that switched off (kernel, then one copy)."""
+    import ctypes
+    from raytracing_amd._lib import check, lib
+    from raytracing_amd.tracer import GRAFT_OUT_U8_RGBA
+    scene, view, keep = rt.pack()
+    out = {"kernel_ms": kernel_ms}
+    px = view.nRows * view.nCols
+    for key, fmt, size in (("u8_rgba", GRAFT_OUT_U8_RGBA, 4), ("f32_rgba", GRAFT_OUT_F32_RGBA, 16), ("f64_rgb", GRAFT_OUT_F64_RGB, 24)):
+        host = ctypes.c_void_p()
+        check(lib.graftHostAlloc(px * size, ctypes.byref(host)))
+        try:
+            call = lambda: check(lib.graftRenderRows(ctypes.byref(scene), ctypes.byref(view), 0, view.nRows, fmt, host, None, None))
+            call()  # (first call: packs, uploads, sizes the device-side frame)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                call()
+            out[key + "_ms"] = (time.perf_counter() - t0) / 2 * 1e3
+            old = raytracing_amd.set_diagnostic("copy_piece_kb", 0)
+            call()
+            t0 = time.perf_counter()
+            call()
+            out[key + "_one_piece_ms"] = (time.perf_counter() - t0) * 1e3
+            raytracing_amd.set_diagnostic("copy_piece_kb", old)
+            out[key + "_bytes"] = px * size
+        finally:
+            lib.graftHostFree(host)
+    del keep
+    return out
+
+
 KERNEL_SOURCES = ("grafthip.hip", "closest_hit.h", "trace_types.h", "pack_tables.h", "host_job.h")
 
 
@@ -304,6 +338,7 @@ def main():
                     "process may use)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-frame512", action="store_true")
+    ap.add_argument("--no-host-frame", action="store_true")
     ap.add_argument("--chunks", type=int, default=None,
                     help="pieces per GPU in the trace/gather pipeline (N > 1); default 8 * sqrt(8 / N)")
     args = ap.parse_args()
@@ -445,6 +480,8 @@ def main():
             out["gathered_frame_tile_rows_checked"] = checked
         if world == 1 and not args.no_frame512:
             out["frame_512"] = frame_512(dev)
+        if world == 1 and not args.no_host_frame:
+            out["host_frame"] = host_frame(rt, kernel_ms)
         if world == 1 and not args.no_cpu:
             cores = args.cpu_cores or host_threads()
             rows = args.cpu_rows

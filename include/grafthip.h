@@ -139,7 +139,8 @@ enum {
     GRAFT_DIAG_GROUP_SIZE = 1,       /* spheres per group of the two-level screens: 0 = chosen per scene, else 4..64, a multiple of 4 */
     GRAFT_DIAG_TILES_PER_TICKET = 2, /* 8x8 tiles a wave draws from the ticket counters at once: 0 = chosen per launch */
     GRAFT_DIAG_TABLE_BUILDS = 4,     /* read-only: screen tables built so far (shows what a re-render re-used) */
-    GRAFT_DIAG_RESERVED_CUS = 5      /* CUs a trace's persistent grid leaves free, 0..128; default 0 (graftRenderFrameMulti uses at least 4) */
+    GRAFT_DIAG_RESERVED_CUS = 5,     /* CUs a trace's persistent grid leaves free, 0..128; default 0 (graftRenderFrameMulti uses at least 4) */
+    GRAFT_DIAG_COPY_PIECE_KB = 6     /* graftRenderRows traces and copies a large frame in pieces of about this many KiB (at most 16 pieces); 0 = one piece; default 65536 */
 };
 GRAFT_API int graftDiagnosticSet(int which, int value);
 GRAFT_API int graftDiagnosticGet(int which); /* -1 for an unknown setting */
@@ -202,7 +203,9 @@ GRAFT_API int graftSynchronize(void);
  * frame buffers (grow-only), and the packed job -- a call whose scene, view and settings equal the previous call's
  * byte for byte packs and uploads nothing; one that differs re-packs into the same device block, re-using the screen
  * tables whose inputs did not change (a key press that toggles anti-aliasing or depth rebuilds none, one that turns
- * the view rebuilds the camera's only). */
+ * the view rebuilds the camera's only).  A frame of more than 128 MiB is traced in up to 16 pieces of rows, each
+ * copied to the host (on a stream of its own) while the next ones are traced; give it a page-locked frameHost
+ * (graftHostAlloc), or the copies cannot overlap anything. */
 GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,
                               void *frameHost, int32_t *hitIndexHost, GraftCounters *countersHost);
 

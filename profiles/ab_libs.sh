@@ -10,7 +10,7 @@ for wl in $WLS; do
   for rep in $(seq 1 ${REPS:-2}); do
     for lib in "" "$OTHER"; do
       cap=$CAP; [ -n "$lib" ] && cap=$OTHER_CAP
-      GRAFT_LIB=$lib timeout -k 10 200 python bench.py --workload $wl --screen $cap --no-cpu --no-frame512 --steps ${STEPS:-5} --warmup 2 2>/dev/null | python -c "
+      GRAFT_LIB=$lib timeout -k 10 200 python bench.py --workload $wl --screen $cap --no-cpu --no-frame512 --no-host-frame --steps ${STEPS:-5} --warmup 2 2>/dev/null | python -c "
 import json,sys
 b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$wl cap $cap', '${lib:-in-tree}', round(b['roofline']['kernel_ms'],4), 'ms', round(b['value']), 'Mrays/s', 'level', b['config']['screen_level'])" || exit 1
     done

@@ -5,7 +5,7 @@
 WLS=${WLS:-cfg4}
 for wl in $WLS; do for rep in $(seq 1 ${REPS:-2}); do for lib in "$@"; do
   [ "$lib" = in-tree ] && lib=""
-  GRAFT_LIB=$lib timeout -k 10 200 python bench.py --workload $wl --no-cpu --no-frame512 --steps ${STEPS:-5} --warmup 2 2>/dev/null | python -c "
+  GRAFT_LIB=$lib timeout -k 10 200 python bench.py --workload $wl --no-cpu --no-frame512 --no-host-frame --steps ${STEPS:-5} --warmup 2 2>/dev/null | python -c "
 import json,sys
 b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$wl', '${lib:-in-tree}', round(b['roofline']['kernel_ms'],4), 'ms', 'level', b['config']['screen_level'])" || exit 1
 done; done; done

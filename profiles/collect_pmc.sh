@@ -11,7 +11,7 @@ OUT=${2:-gpurun_out/pmc_$WL}
 CAP=${3:-4}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="bench.py --workload $WL --screen $CAP --no-cpu --no-frame512 --steps 1 --warmup 0"
+ARGS="bench.py --workload $WL --screen $CAP --no-cpu --no-frame512 --no-host-frame --steps 1 --warmup 0"
 pass() {
     local name=$1; shift
     timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 $ARGS > "$OUT/$name.log" 2>&1

@@ -799,6 +799,8 @@ struct Device {
     int id = -1, numCU = 0;
     hipStream_t stream = nullptr;
     Reusable frame, index, counters;      // device side of graftRenderRows' host buffers
+    hipStream_t copyStream = nullptr;     // graftRenderRows: finished pieces of a large frame leave on it while the next are traced
+    hipEvent_t pieceTraced[16] = {nullptr};
     Reusable arena;                       // device block of the job graftRenderRows keeps between calls
     std::vector<unsigned char> cacheKey;  // the input that job was packed from
     GraftJob *cacheJob = nullptr;
@@ -951,6 +953,8 @@ int initDevice(int device, Device **out) {
             HIP_TRY(hipGetDeviceProperties(&prop, device));
             D.numCU = prop.multiProcessorCount;
             HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&D.copyStream, hipStreamNonBlocking));
+            for (hipEvent_t &e : D.pieceTraced) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             static_assert(sizeof(scratch) == kScratchBytes, "scratch size");
             HIP_TRY(hipGetSymbolAddress((void **)&D.scratch, HIP_SYMBOL(scratch)));  // this device's copy of the array
             HIP_TRY(hipHostMalloc((void **)&D.scratchStage, kScratchBytes, hipHostMallocDefault));
@@ -975,6 +979,15 @@ void releaseDevice(Device &D) {
     if (D.stream) {
         (void)hipStreamSynchronize(D.stream);
         (void)hipStreamDestroy(D.stream);
+    }
+    if (D.copyStream) {
+        (void)hipStreamSynchronize(D.copyStream);
+        (void)hipStreamDestroy(D.copyStream);
+    }
+    D.copyStream = nullptr;
+    for (hipEvent_t &e : D.pieceTraced) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
     }
     if (D.comm && gRccl.commDestroy) (void)gRccl.commDestroy(D.comm);
     D.comm = nullptr;
@@ -1121,6 +1134,10 @@ GRAFT_API int graftDiagnosticSet(int which, int value) {
             if (value < 0 || value > 128) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: %d reserved CUs", value);
             gSettings.reservedCUs = value;
             return GRAFT_OK;
+        case GRAFT_DIAG_COPY_PIECE_KB:
+            if (value < 0) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: copy pieces of %d KiB", value);
+            gSettings.copyPieceKB = value;
+            return GRAFT_OK;
         default:
             return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: unknown setting %d", which);
     }
@@ -1133,6 +1150,7 @@ GRAFT_API int graftDiagnosticGet(int which) {
         case GRAFT_DIAG_GROUP_SIZE: return gSettings.groupSize;
         case GRAFT_DIAG_TILES_PER_TICKET: return gSettings.tilesPerTicket;
         case GRAFT_DIAG_RESERVED_CUS: return gSettings.reservedCUs;
+        case GRAFT_DIAG_COPY_PIECE_KB: return gSettings.copyPieceKB;
         case GRAFT_DIAG_TABLE_BUILDS: return (int)(gTables.builds & 0x7fffffff);
         default: return -1;
     }
@@ -1325,11 +1343,45 @@ GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, in
         HIP_TRY(hipMemsetAsync(D->counters.ptr, 0, sizeof(GraftCounters), D->stream));
         dCnt = (GraftCounters *)D->counters.ptr;
     }
-    rc = launchTrace(job, row0, nRows, format, D->frame.ptr, dIdx, dCnt, D->stream);
-    if (rc == GRAFT_OK && (e = hipMemcpyAsync(frameHost, D->frame.ptr, frameBytes, hipMemcpyDeviceToHost, D->stream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(frame): %s", hipGetErrorString(e));
-    if (rc == GRAFT_OK && dIdx && (e = hipMemcpyAsync(hitIndexHost, dIdx, px * 4, hipMemcpyDeviceToHost, D->stream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(index): %s", hipGetErrorString(e));
+    // A large frame is traced in pieces of rows, and every finished piece leaves for the host (on the copy stream,
+    // behind an event) while the next ones are traced: the copy of a 16384 x 16384 frame takes about as long as its
+    // trace, and one after the other they would double the call.  Pieces of about copyPieceKB of frame each (0: the
+    // whole band in one piece), at most 16; small frames are one piece, whose launch and copy are as before.
+    const int nCols = job->P.nCols;
+    int pieces = 1;
+    if (gSettings.copyPieceKB > 0) {
+        const size_t want = frameBytes / ((size_t)gSettings.copyPieceKB << 10);
+        pieces = (int)(want < 1 ? 1 : want > 16 ? 16 : want);
+    }
+    const int tileRows = (nRows + kTile - 1) / kTile;
+    if (pieces > tileRows) pieces = tileRows;
+    const size_t pixelBytes = graftPixelBytes(format);
+    for (int k = 0; k < pieces && rc == GRAFT_OK; ++k) {
+        const int r0 = (int)((long long)k * tileRows / pieces) * kTile;
+        int r1 = (int)((long long)(k + 1) * tileRows / pieces) * kTile;
+        if (r1 > nRows) r1 = nRows;
+        if (r1 <= r0) continue;
+        const size_t firstPx = (size_t)r0 * nCols, px1 = (size_t)(r1 - r0) * nCols;
+        unsigned char *dFrame = (unsigned char *)D->frame.ptr + firstPx * pixelBytes;
+        rc = launchTrace(job, row0 + r0, r1 - r0, format, dFrame, dIdx ? dIdx + firstPx : nullptr, dCnt, D->stream);
+        if (rc != GRAFT_OK) break;
+        hipStream_t out = D->stream;
+        if (pieces > 1) {  // the copy waits for this piece's kernel only
+            out = D->copyStream;
+            if ((e = hipEventRecord(D->pieceTraced[k], D->stream)) != hipSuccess ||
+                (e = hipStreamWaitEvent(out, D->pieceTraced[k], 0)) != hipSuccess) {
+                rc = fail(GRAFT_ERR_HIP, "graftRenderRows: ordering a copy behind its piece: %s", hipGetErrorString(e));
+                break;
+            }
+        }
+        if ((e = hipMemcpyAsync((unsigned char *)frameHost + firstPx * pixelBytes, dFrame, px1 * pixelBytes, hipMemcpyDeviceToHost, out)) != hipSuccess)
+            rc = fail(GRAFT_ERR_HIP, "hipMemcpy(frame): %s", hipGetErrorString(e));
+        if (rc == GRAFT_OK && dIdx && (e = hipMemcpyAsync(hitIndexHost + firstPx, dIdx + firstPx, px1 * 4, hipMemcpyDeviceToHost, out)) != hipSuccess)
+            rc = fail(GRAFT_ERR_HIP, "hipMemcpy(index): %s", hipGetErrorString(e));
+    }
     if (rc == GRAFT_OK && dCnt && (e = hipMemcpyAsync(countersHost, dCnt, sizeof(GraftCounters), hipMemcpyDeviceToHost, D->stream)) != hipSuccess) rc = fail(GRAFT_ERR_HIP, "hipMemcpy(counters): %s", hipGetErrorString(e));
     if ((e = hipStreamSynchronize(D->stream)) != hipSuccess && rc == GRAFT_OK) rc = fail(GRAFT_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    if (pieces > 1 && (e = hipStreamSynchronize(D->copyStream)) != hipSuccess && rc == GRAFT_OK) rc = fail(GRAFT_ERR_HIP, "hipStreamSynchronize(copies): %s", hipGetErrorString(e));
     return rc;
 }
 

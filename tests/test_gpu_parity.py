@@ -126,6 +126,43 @@ def test_bands_equal_whole_frame(gpu):
         assert np.array_equal(np.concatenate([p[1] for p in parts]), widx)
 
 
+def test_frame_copied_in_pieces_equals_one_piece(gpu):
+    """graftRenderRows traces a large frame in pieces of rows and copies each to the host while the next are traced;
+    with the piece size turned down a small frame goes the same way: frame, index plane and counters as in one piece,
+    for bands that do and do not start at row 0, into pageable and into page-locked memory."""
+    import ctypes
+    from raytracing_amd import get_diagnostic, set_diagnostic
+    from raytracing_amd._lib import check, lib
+    rt = build("small_96x64_aa3")
+    old = get_diagnostic("copy_piece_kb")
+    try:
+        set_diagnostic("copy_piece_kb", 0)
+        whole, widx = rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_index=True, want_counters=True)
+        counters = rt.last_counters, rt.last_rays_traced
+        set_diagnostic("copy_piece_kb", 16)      # 144 KiB of doubles: 8 pieces (one per row of tiles)
+        rgb, idx = rt.render_rows(0, None, GRAFT_OUT_F64_RGB, want_index=True, want_counters=True)
+        assert np.array_equal(rgb.view(np.uint64), whole.view(np.uint64)) and np.array_equal(idx, widx)
+        assert (rt.last_counters, rt.last_rays_traced) == counters
+        part, pidx = rt.render_rows(13, 40, GRAFT_OUT_F64_RGB, want_index=True)
+        assert np.array_equal(part.view(np.uint64), whole[13:53].view(np.uint64)) and np.array_equal(pidx, widx[13:53])
+        u8 = rt.render_rows(0, None, GRAFT_OUT_U8_RGBA)
+        assert np.array_equal(u8[..., :3], quant8(whole))
+        # page-locked destination: the copies really run beside the kernels
+        scene, view, keep = rt.pack()
+        nbytes = view.nRows * view.nCols * 24
+        host = ctypes.c_void_p()
+        check(lib.graftHostAlloc(nbytes, ctypes.byref(host)))
+        try:
+            check(lib.graftRenderRows(ctypes.byref(scene), ctypes.byref(view), 0, view.nRows, GRAFT_OUT_F64_RGB, host, None, None))
+            got = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_double)), shape=(view.nRows, view.nCols, 3))
+            assert np.array_equal(got.view(np.uint64), whole.view(np.uint64))
+        finally:
+            lib.graftHostFree(host)
+        del keep
+    finally:
+        set_diagnostic("copy_piece_kb", old)
+
+
 def test_device_sqrt_and_divide_are_correctly_rounded(gpu):
     """The path needs IEEE sqrt and divide on the device (vector.c:67-82, shapes.c:58, :88 on the CPU)."""
     import ctypes
