@@ -31,6 +31,7 @@
 #include "closest_hit.h"
 #include "pack_tables.h"
 #include "host_job.h"
+#include "host_steps.h"
 
 using namespace graft;
 
@@ -1026,8 +1027,8 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     TraceParams P = job->P;
     P.row0 = row0; P.bandRows = nRows; P.format = format;
     P.frame = frame; P.hitIndex = hitIndex; P.counters = (unsigned long long *)counters;
-    P.tilesX = (P.nCols + kTile - 1) / kTile;
-    const long long tiles = (long long)P.tilesX * ((nRows + kTile - 1) / kTile);
+    P.tilesX = (int)(((long long)P.nCols + kTile - 1) / kTile);
+    const long long tiles = (long long)P.tilesX * (((long long)nRows + kTile - 1) / kTile);
     if (tiles > 0x7fff0000LL) return fail(GRAFT_ERR_ARG, "graftJobTrace: %lld tiles in one launch", tiles);
     P.numTiles = (int)tiles;
     const int wavesPerBlock = job->block / 64;
@@ -1193,34 +1194,13 @@ GRAFT_API size_t graftPixelBytes(int format) {
 
 // ---- host-side steps of launchRays ----
 
-GRAFT_API int graftLoopOffsets(double extent, int n, double *out, int cap) {
-    if (!(extent > 0) || !std::isfinite(extent) || n <= 0) return -1;
-    int count = 0;
-    for (double i = -extent / 2; i < extent / 2; i = i + extent / n) {  // mainTracing.c:392
-        if (out && count < cap) out[count] = i;
-        if (++count > 2 * n + 16) return -1;
-    }
-    return count;
-}
+GRAFT_API int graftLoopOffsets(double extent, int n, double *out, int cap) { return loopOffsets(extent, n, out, cap); }
 
-GRAFT_API int graftScreenCoord(double coord, int n, double extent) {  // mainTracing.c:89-100
-    double ratio = n / extent;
-    coord = round(coord * ratio);
-    return (int)(coord + n / 2);
-}
-
-static void hostNewPoint(const double start[3], const double dir[3], double dist, double out[3]) {
-    double den = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];  // mainTracing.c:107
-    double scalar = dist < 0 ? -sqrt(dist * dist / den) : sqrt(dist * dist / den);
-    for (int c = 0; c < 3; ++c) out[c] = start[c] + scalar * dir[c];
-}
+GRAFT_API int graftScreenCoord(double coord, int n, double extent) { return screenCoord(coord, n, extent); }
 
 GRAFT_API void graftCamInitialize(const double target[3], const double viewDir[3], double targetToScreen,
                                   double screenToCam, double screenCenter[3], double camPos[3]) {
-    double sc[3];
-    hostNewPoint(target, viewDir, targetToScreen, sc);  // mainTracing.c:381
-    hostNewPoint(sc, viewDir, screenToCam, camPos);     // mainTracing.c:383
-    for (int c = 0; c < 3; ++c) screenCenter[c] = sc[c];
+    camInitializeHost(target, viewDir, targetToScreen, screenToCam, screenCenter, camPos);
 }
 
 // ---- pinned host memory ----
@@ -1353,7 +1333,7 @@ GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, in
         const size_t want = frameBytes / ((size_t)gSettings.copyPieceKB << 10);
         pieces = (int)(want < 1 ? 1 : want > 16 ? 16 : want);
     }
-    const int tileRows = (nRows + kTile - 1) / kTile;
+    const int tileRows = (int)(((long long)nRows + kTile - 1) / kTile);
     if (pieces > tileRows) pieces = tileRows;
     const size_t pixelBytes = graftPixelBytes(format);
     for (int k = 0; k < pieces && rc == GRAFT_OK; ++k) {
@@ -1415,33 +1395,7 @@ GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *v
 
 GRAFT_API int graftFramePlan(int nRows, int nDevices, int piecesPerDevice, int *firstRow, int *rows, int *owner,
                              int *rowInOwner, int *ownedRows, int cap) {
-    if (nRows <= 0 || nDevices <= 0) return -1;
-    const int tiles = (nRows + kTile - 1) / kTile;
-    int count = nDevices * (piecesPerDevice > 1 ? piecesPerDevice : 1);
-    if (count > tiles) count = tiles;
-    if (count < 1) count = 1;
-    if (ownedRows)
-        for (int d = 0; d < nDevices; ++d) ownedRows[d] = 0;
-    std::vector<int> owned((size_t)nDevices, 0);
-    int out = 0;
-    for (int k = 0; k < count; ++k) {
-        const int r0 = (int)((long long)k * tiles / count) * kTile;
-        int r1 = (int)((long long)(k + 1) * tiles / count) * kTile;
-        if (r1 > nRows) r1 = nRows;
-        if (r1 <= r0) continue;
-        const int who = k % nDevices;
-        if (out < cap) {
-            if (firstRow) firstRow[out] = r0;
-            if (rows) rows[out] = r1 - r0;
-            if (owner) owner[out] = who;
-            if (rowInOwner) rowInOwner[out] = owned[who];
-        }
-        owned[who] += r1 - r0;
-        ++out;
-    }
-    if (ownedRows)
-        for (int d = 0; d < nDevices; ++d) ownedRows[d] = owned[d];
-    return out;
+    return framePlan(nRows, nDevices, piecesPerDevice, firstRow, rows, owner, rowInOwner, ownedRows, cap);
 }
 
 GRAFT_API int graftFramePieces(int nRows, int nDevices, int piecesPerDevice, int *firstRow, int *rows, int *owner, int cap) {

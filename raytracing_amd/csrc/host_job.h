@@ -336,7 +336,7 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     std::vector<unsigned char> mask((size_t)nL * (nS > 0 ? nS : 1) + 1, 0);
     for (int i = 0; i < nL; ++i) {
         const GraftLight &l = scene->lights[i];
-        if (l.avoidNum < 0 || l.avoidOffset < 0 || l.avoidOffset + l.avoidNum > scene->avoidIndexLen ||
+        if (l.avoidNum < 0 || l.avoidOffset < 0 || (long long)l.avoidOffset + l.avoidNum > scene->avoidIndexLen ||
             (l.avoidNum > 0 && !scene->avoidIndex))
             return fail(GRAFT_ERR_ARG, "light %d avoid slice [%d,+%d) outside %d", i, l.avoidOffset, l.avoidNum,
                         scene->avoidIndexLen);

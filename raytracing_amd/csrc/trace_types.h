@@ -1,8 +1,11 @@
 // trace_types.h -- constants and plain structs shared by the device code and the host-side packers of
-// libgrafthip.so (included by grafthip.hip only).
+// libgrafthip.so (included by grafthip.hip, and -- without the device-only declarations -- by the host-only
+// sanitizer build of the packers, tests/host_asan).
 #pragma once
 
+#ifdef __HIPCC__
 #include <hip/hip_runtime.h>
+#endif
 
 #include <cstddef>
 
@@ -77,7 +80,9 @@ struct DevCamera {
 
 // The same block seen as doubles in the constant address space: loads through this view are scalar loads whatever
 // else the kernel stores to global memory (the block is written before the launch and never by a kernel).
+#ifdef __HIPCC__
 typedef const double __attribute__((address_space(4))) *ConstDoubles;
+#endif
 enum { CAM_SCREEN = 0, CAM_POS = 3, CAM_VIEW = 6, CAM_LR = 9, CAM_UD = 12, CAM_LRDEN = 15, CAM_UDDEN = 16, CAM_BACKGROUND = 17,
        CAM_SUBX = 20, CAM_SUBY = 21, CAM_TOSCREEN = 22, CAM_LRUNIT = 25, CAM_UDUNIT = 28 };
 static_assert(offsetof(DevCamera, camPos) == 8 * CAM_POS && offsetof(DevCamera, udVec) == 8 * CAM_UD &&
@@ -153,9 +158,11 @@ struct TraceParams {
     int *tileCursor;
 };
 
+#ifdef __HIPCC__
 extern __shared__ __attribute__((aligned(32))) double ldsGeom[];
 
 typedef double double4v __attribute__((ext_vector_type(4)));
+#endif
 
 enum { M_RADIANCE = 0, M_SHADOW = 1, M_INDEX = 2, M_DONE = 3 };
 enum { F_MIRROR_PENDING = 1, F_HAS_REFRACTION = 2, F_REFRACTION_REFLECTS = 4 };
