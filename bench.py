@@ -312,16 +312,20 @@ def host_threads():
 
 def rank_diagnostics(per_step, steps, local_rays, step_ms, world, dev):
     """What every rank did per frame: its rays, the device time of its own kernels (first launch to last kernel done,
-    the transfers queued between them included), the host time spent waiting for transfers after the last kernel was
+    the transfers queued between them included), the device time from its last kernel's end to its last transfer's
+    end (the part of the exchange that no tracing on that rank hid), the host time spent after the last kernel was
     queued, and the whole step.  Collective: every rank calls it."""
     mine = torch.tensor([local_rays,
                          sum(d["trace_event"][0].elapsed_time(d["trace_event"][1]) for d in per_step) / steps,
                          sum(d["wait_s"] for d in per_step) / steps * 1e3, step_ms,
-                         sum(d["pieces"] for d in per_step) / steps], dtype=torch.float64, device=dev)
+                         sum(d["pieces"] for d in per_step) / steps,
+                         sum(d["tail_event"][0].elapsed_time(d["tail_event"][1]) for d in per_step) / steps],
+                        dtype=torch.float64, device=dev)
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
     return [{"rank": r, "rays": int(g[0]), "trace_ms": float(g[1]), "transfer_wait_ms": float(g[2]),
-             "step_ms": float(g[3]), "pieces": int(g[4])} for r, g in enumerate(gathered)]
+             "step_ms": float(g[3]), "pieces": int(g[4]), "last_kernel_to_last_transfer_ms": float(g[5])}
+            for r, g in enumerate(gathered)]
 
 
 def main():
@@ -341,6 +345,9 @@ def main():
     ap.add_argument("--no-host-frame", action="store_true")
     ap.add_argument("--chunks", type=int, default=None,
                     help="pieces per GPU in the trace/gather pipeline (N > 1); default 8 * sqrt(8 / N)")
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="compute units every trace leaves free (default: 4 at N > 1, where RCCL's transfer kernels "
+                         "run beside the traces; 0 on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -359,6 +366,9 @@ def main():
     dev = torch.device("cuda", local)
     raytracing_amd.init(local)
     raytracing_amd.set_diagnostic("screen_cap", args.screen)
+    if args.reserve_cus is None:
+        args.reserve_cus = 4 if world > 1 else 0
+    raytracing_amd.set_diagnostic("reserved_cus", args.reserve_cus)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
@@ -442,8 +452,10 @@ def main():
                                                             "reference makes %.4g for the same frame, see `reference`"
                                                             % (rays, ref_rays),
                                             "parallelism": ("1 GPU" if world == 1 else "rows dealt round-robin in %d pieces per GPU x%d, "
-                                                            "RCCL send/recv to rank 0 pipelined behind tracing"
-                                                            % (args.chunks, world))},
+                                                            "RCCL send/recv to rank 0 queued behind each piece, "
+                                                            "%d CUs per GPU left free for them"
+                                                            % (args.chunks, world, args.reserve_cus)),
+                                            "reserved_cus": args.reserve_cus},
             "rays_per_frame": rays, "tests_per_frame": tests,
             "reference": {"rays_per_frame": ref_rays,
                           "equivalent_Mrays_per_s": ref_rays / (elapsed / args.steps) / 1e6,

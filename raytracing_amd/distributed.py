@@ -103,8 +103,11 @@ def trace_and_gather(trace, local, frame, n_rows, world, rank, chunks=8, group=N
     [rows][cols][channels] view) on the current stream.  `local` is this rank's [local_rows][cols][channels] buffer
     (ignored on rank 0, which traces into `frame`, the whole [n_rows][cols][channels] tensor).  The transfers are
     queued behind the piece's kernel (RCCL waits for the current stream at the time of the call) and only waited
-    for at the end of the frame, so on a strong-scaled frame the exchange hides behind the tracing of the later
-    pieces.  Every rank derives the same piece list, so sends and receives pair up in order."""
+    for at the end of the frame, so the exchange of a piece can run beside the tracing of the later pieces.  RCCL's
+    transfers are kernels: they only run beside a trace that leaves compute units free for them (the library's
+    `reserved_cus` diagnostic; without it a transfer waits for the trace in flight to drain).  `stats`, when given,
+    receives `trace_event` (first launch, last kernel done), `tail_event` (last kernel done, last transfer done),
+    `wait_s` and `pieces`.  Every rank derives the same piece list, so sends and receives pair up in order."""
     if world == 1:
         trace(0, n_rows, frame)
         return
@@ -133,6 +136,11 @@ def trace_and_gather(trace, local, frame, n_rows, world, rank, chunks=8, group=N
         last.record()
         t0 = time.perf_counter()
     for w in works:
-        w.wait()
+        w.wait()  # the current stream now waits for the transfer; the host does not
     if stats is not None:
-        stats.update(trace_event=(first, last), wait_s=time.perf_counter() - t0, pieces=len(mine))
+        # `last` completes with this rank's last kernel (the transfers run on RCCL's own stream), `done` with the
+        # last transfer: the time between them is the part of the exchange that no tracing on this rank hid
+        done = torch.cuda.Event(enable_timing=True)
+        done.record()
+        stats.update(trace_event=(first, last), tail_event=(last, done), wait_s=time.perf_counter() - t0,
+                     pieces=len(mine))

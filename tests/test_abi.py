@@ -74,3 +74,29 @@ def test_product_neither_imports_nor_links_the_oracle():
     needed = subprocess.run(["readelf", "-d", os.path.join(root, "raytracing_amd", "csrc", "libgrafthip.so")],
                             capture_output=True, text=True, check=True).stdout
     assert "NEEDED" in needed and "oracle" not in needed.lower()
+
+
+def test_integration_table_names_and_arities_match_the_header():
+    """Every `graft*(...)` signature quoted in INTEGRATION.md names a function the header declares, with as many
+    parameters as the header gives it (a reader who binds from the table must not be led astray)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "grafthip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    declared = {}
+    for m in re.finditer(r"GRAFT_API\s+[\w\s\*]+?\b(graft\w+)\s*\(([^;]*?)\)\s*;", header, flags=re.S):
+        params = m.group(2).strip()
+        declared[m.group(1)] = 0 if params in ("", "void") else params.count(",") + 1
+    assert len(declared) >= 25
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    quoted = re.findall(r"`(graft\w+)\(([^`]*)\)`", text)
+    assert len(quoted) >= 20
+    for name, args in quoted:
+        assert name in declared, "INTEGRATION.md quotes %s, which include/grafthip.h does not declare" % name
+        if args.strip() in ("...", "…"):
+            continue
+        arity = 0 if not args.strip() else args.count(",") + 1
+        assert arity == declared[name], "%s: %d arguments in INTEGRATION.md, %d in the header" % (name, arity, declared[name])
+    # and nothing the header exports is missing from the document
+    for name in declared:
+        assert name in text, "%s is not mentioned in INTEGRATION.md" % name

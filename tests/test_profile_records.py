@@ -24,11 +24,37 @@ def test_record_matches_the_sources_and_gives_fractions(path):
     rec = json.load(open(path))
     assert rec["kernel_source_hash"] == bench.kernel_source_hash(), \
         "%s was recorded on other kernel sources: run profiles/collect_all.sh and profiles/summarize_pmc.py" % path
-    kernel_ms = rec["kernel_trace"]["average_ns"] / 1e6
+    kernel_ms = rec["kernel_trace"]["warm_average_ns"] / 1e6
     roof = bench.roofline(rec, "test", kernel_ms, local_tests=1)
     assert 0 < roof["frac"] <= 1
     assert 0 < roof["fp64_issue_frac"] <= 1
     assert roof["frac"] <= 2 * roof["fp64_issue_frac"] + 1e-12  # an instruction is worth at most two flops
-    assert 0 < roof["valu_busy"] <= 1 and 0 < roof["lane_utilisation"] <= 1
-    # the two independent timings of the record (counter pass, kernel trace) agree
-    assert abs(rec["derived"]["kernel_ms"] - kernel_ms) <= 0.25 * kernel_ms
+    # (the busy fraction divides two counters of different granularity -- busy cycles per shader engine, VALU cycles per
+    # SIMD -- and can come out a few percent above 1 on a launch whose engines finish at different times)
+    assert 0 < roof["valu_busy"] <= 1.1 and 0 < roof["lane_utilisation"] <= 1
+    # The trace pass runs the bench with warm-up steps; its timed steps are the last launches in the kernel trace.  Their
+    # average and the bench's own HIP-event time for the same steps agree to 3 %.
+    trace, under = rec["kernel_trace"], rec["bench_under_trace"]
+    assert trace["warm_calls"] == under["steps"] >= 10
+    warm_ms = trace["warm_average_ns"] / 1e6
+    assert abs(warm_ms - under["kernel_ms"]) <= 0.03 * warm_ms, (warm_ms, under["kernel_ms"])
+    assert abs(rec["derived"]["kernel_ms"] - warm_ms) < 1e-9
+
+
+@pytest.mark.parametrize("path", RECORDS, ids=[os.path.basename(p) for p in RECORDS])
+def test_kernel_stats_file_beside_the_record(path):
+    """The rocprofv3 --kernel-trace --stats summary of the record's trace pass is kept beside it, and the rows of the
+    trace kernel extracted from the trace give the record's warm average."""
+    import csv
+    import glob as g
+    stem = os.path.basename(path)[len("pmc_"):-len(".json")]
+    stats = g.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_stats.csv" % stem))
+    rows = g.glob(os.path.join(ROOT, "profiles", "r*_%s_trace_kernel_rows.csv" % stem))
+    assert stats and rows, "no kernel-trace summary for %s: run profiles/publish_records.sh" % stem
+    rec = json.load(open(path))
+    durations = [int(r["duration_ns"]) for r in csv.DictReader(open(sorted(rows)[-1]))]
+    steps = rec["bench_under_trace"]["steps"]
+    assert abs(sum(durations[-steps:]) / steps - rec["kernel_trace"]["warm_average_ns"]) < 1.0
+    with open(sorted(stats)[-1]) as f:
+        trace_rows = [r for r in csv.DictReader(f) if "traceKernel" in r["Name"]]
+    assert trace_rows and int(trace_rows[0]["Calls"]) == len(durations)
