@@ -267,6 +267,10 @@ GRAFT_API size_t graftPixelBytes(int format);
  * the x86 divide are for the reference (vector.c:67-82, shapes.c:58, :88). */
 GRAFT_API int graftProbeSqrt(const double *a, double *out, size_t n);
 GRAFT_API int graftProbeDiv(const double *a, const double *b, double *out, size_t n);
+/* out[3i..3i+2] = vecUnit of v[3i..3i+2] (vector.c:74-82; left at zero when the length is not positive) as the hot
+ * stages of the kernels evaluate it: the square root without the rescaling a vector of ordinary length never needs,
+ * the three quotients through one refined reciprocal.  Must equal sqrt and `/` bit for bit. */
+GRAFT_API int graftProbeUnit(const double *v, double *out, size_t n);
 
 #ifdef __cplusplus
 }

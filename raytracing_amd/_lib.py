@@ -106,6 +106,7 @@ lib.graftPixelBytes.argtypes = [ctypes.c_int]
 lib.graftPixelBytes.restype = ctypes.c_size_t
 lib.graftProbeSqrt.argtypes = [c_double_p, c_double_p, ctypes.c_size_t]
 lib.graftProbeDiv.argtypes = [c_double_p, c_double_p, c_double_p, ctypes.c_size_t]
+lib.graftProbeUnit.argtypes = [c_double_p, c_double_p, ctypes.c_size_t]
 
 
 def check(code):

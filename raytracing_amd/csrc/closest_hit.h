@@ -27,16 +27,37 @@ __device__ __forceinline__ void unit3(double vx, double vy, double vz, double &o
     }
 }
 
+// sqrt(x) for 2^-700 < x < 2^700: the sequence the compiler emits for a double-precision square root (reciprocal square
+// root, one coupled Newton step on root and half-reciprocal, two corrections of the root: correctly rounded) without the
+// rescaling of arguments below 2^-767 and the special cases 0 and infinity around it, which such an argument never
+// takes -- 8 instructions of 22.  Bit for bit the value `sqrt` returns (probed on the device against it).
+__device__ __forceinline__ double sqrtInRange(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return g;
+}
+
 // vecUnit again, for the hot stages: the three quotients share the divisor, and so does most of the division the
-// compiler emits for each (scale, reciprocal, two Newton steps on the divisor alone).  With the length and the three
-// components all between 2^-400 and 2^400 nothing is scaled and no special case arises, and the remaining steps per
-// component -- q = x r, e = fma(-m, q, x), q' = fma(e, r, q) -- are the sequence's own: the result is the correctly
-// rounded quotient, bit for bit what `/` gives.  Anything else (a zero component among them) takes `/`.
+// compiler emits for each (scale, reciprocal, two Newton steps on the divisor alone).  With the squared length between
+// 2^-700 and 2^700 and the three components all above 2^-400 nothing is scaled and no special case arises -- neither in
+// the square root (sqrtInRange) nor in the quotients --, and the remaining steps per component -- q = x r,
+// e = fma(-m, q, x), q' = fma(e, r, q) -- are the division sequence's own: the result is the correctly rounded
+// quotient, bit for bit what `/` gives.  Anything else (a zero component among them) takes `sqrt` and `/`.
 __device__ __forceinline__ void unit3Shared(double vx, double vy, double vz, double &ox, double &oy, double &oz) {
-    const double mag = sqrt(dot3(vx, vy, vz, vx, vy, vz));
-    const double lo = 0x1p-400, hi = 0x1p400;
+    const double ss = dot3(vx, vy, vz, vx, vy, vz);
+    const double lo = 0x1p-400;
     const double ax = fabs(vx), ay = fabs(vy), az = fabs(vz);
-    if (mag > lo && mag < hi && fmin(ax, fmin(ay, az)) > lo) {  // (components never exceed the length by more than rounding)
+    if (ss > 0x1p-700 && ss < 0x1p700 && fmin(ax, fmin(ay, az)) > lo) {  // (components never exceed the length by more than rounding)
+#ifdef GRAFT_PLAIN_SQRT
+        const double mag = sqrt(ss);
+#else
+        const double mag = sqrtInRange(ss);
+#endif
         double r = __builtin_amdgcn_rcp(mag);
         r = __builtin_fma(__builtin_fma(-mag, r, 1.0), r, r);
         r = __builtin_fma(__builtin_fma(-mag, r, 1.0), r, r);
@@ -44,10 +65,13 @@ __device__ __forceinline__ void unit3Shared(double vx, double vy, double vz, dou
         ox = __builtin_fma(__builtin_fma(-mag, qx, vx), r, qx);
         oy = __builtin_fma(__builtin_fma(-mag, qy, vy), r, qy);
         oz = __builtin_fma(__builtin_fma(-mag, qz, vz), r, qz);
-    } else if (mag > 0) {
-        ox = vx / mag;
-        oy = vy / mag;
-        oz = vz / mag;
+    } else {
+        const double mag = sqrt(ss);
+        if (mag > 0) {
+            ox = vx / mag;
+            oy = vy / mag;
+            oz = vz / mag;
+        }
     }
 }
 

@@ -228,6 +228,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     int usedUp = 0;  // counters found empty so far (wave-uniform)
     if (MANYCURSORS && P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
     int tile = 0, tileEnd = 0;
+    int listEnd = 0;  // MANYCURSORS with candidate lists: the tile list in LDS covers tiles [.., listEnd) of this ticket
     for (;;) {
         if (tile >= tileEnd) {
             if (MANYCURSORS) {
@@ -242,6 +243,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 if (ticket >= numTickets) break;  // every wave gets here: the counters only grow
                 tile = ticket * P.tilesPerTicket;
                 tileEnd = min(tile + P.tilesPerTicket, P.numTiles);
+                listEnd = tile;
                 if (P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
             } else {
                 const int ticket = __builtin_amdgcn_readfirstlane(nextTicket);
@@ -258,8 +260,23 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         const bool inside = ix < P.nCols && by < P.bandRows;
 
         const ConstDoubles cam = cameraView(P);
-        if (LISTS) {  // what this tile's primary rays can see, worked out once by all lanes together
-            const int ix0 = tx * kTile, ix1 = min(ix0 + kTile, P.nCols) - 1;
+        // What this tile's primary rays can see, worked out once by all lanes together.  Cheap tiles (a ticket of several
+        // tiles, few samples per pixel) share one list per run of a ticket's tiles in one row of tiles: the list costs as
+        // much as tracing a tile's 64 rays, and a rectangle a few tiles wide sees hardly more spheres than one tile.
+        // (Not in the kernels with mirrors: measured 5 % slower there -- their register allocation is tight, and the
+        // tile list is a small part of what they do.)
+#ifdef GRAFT_LIST_PER_TILE  // (A/B builds: one list per tile whatever the ticket)
+        constexpr bool kSharedLists = false;
+#else
+        constexpr bool kSharedLists = MANYCURSORS && !MIRRORS;
+#endif
+        if (LISTS && (!kSharedLists || tile >= listEnd)) {
+            int lastTx = tx;
+            if (kSharedLists) {
+                listEnd = min(tileEnd, (ty + 1) * P.tilesX);
+                lastTx = listEnd - 1 - ty * P.tilesX;
+            }
+            const int ix0 = tx * kTile, ix1 = min(lastTx * kTile + kTile, P.nCols) - 1;
             const int iy0 = P.row0 + ty * kTile, iy1 = P.row0 + min(ty * kTile + kTile, P.bandRows) - 1;
             // samples lie at the pixel's offsets plus 0 (the mask ray) .. numPasses sub-steps (mainTracing.c:405-406)
             const double spanX = P.aliasing ? cam[CAM_SUBX] * (double)P.numPasses : 0.0;
@@ -747,6 +764,14 @@ __global__ void probeDivKernel(const double *a, const double *b, double *out, si
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] / b[i];
 }
+__global__ void probeUnitKernel(const double *v, double *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double x = 0, y = 0, z = 0;  // (left at zero when the length is not positive, vector.c:76)
+        unit3Shared(v[3 * i], v[3 * i + 1], v[3 * i + 2], x, y, z);
+        out[3 * i] = x; out[3 * i + 1] = y; out[3 * i + 2] = z;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // host side
@@ -1061,9 +1086,10 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     long long maxBlocks = (long long)(D->numCU - reserved > 1 ? D->numCU - reserved : 1) * blocksPerCU;
     const int grid = (int)(wantBlocks < maxBlocks ? wantBlocks : maxBlocks);
     const long long waves = (long long)grid * wavesPerBlock;
-    // tiles per ticket: 1 for expensive tiles, 2 for cheap ones, but never so many that a wave gets fewer than 8 draws
+    // tiles per ticket: 1 for expensive tiles, 2 or 4 for cheap ones, but never so many that a wave gets fewer than 8 draws
     // (load balance at the end of the launch)
-    long long perTicket = manyCursors ? 2 : 1;
+    // (with candidate lists a ticket's tiles share one tile list per row of tiles: longer tickets)
+    long long perTicket = manyCursors ? (job->screen >= 6 && !job->mirrors ? 4 : 2) : 1;
     if (perTicket * waves * 8 > tiles) perTicket = tiles / (waves * 8) < 1 ? 1 : tiles / (waves * 8);
     if (gSettings.tilesPerTicket > 0) perTicket = gSettings.tilesPerTicket;  // diagnostics: forced ticket size
     P.tilesPerTicket = (int)perTicket;
@@ -1660,6 +1686,26 @@ static int probe(int which, const double *a, const double *b, double *out, size_
     };
     const int rc = run();
     (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dO);  // on every path
+    return rc;
+}
+
+GRAFT_API int graftProbeUnit(const double *v, double *out, size_t n) {
+    if (!gBound) return fail(GRAFT_ERR_STATE, "probe: call graftInit first");
+    if (!v || !out || n == 0) return fail(GRAFT_ERR_ARG, "probe: null argument");
+    hipStream_t stream = gBound->stream;
+    double *dV = nullptr, *dO = nullptr;
+    auto run = [&]() -> int {
+        HIP_TRY(hipMalloc((void **)&dV, n * 24));
+        HIP_TRY(hipMalloc((void **)&dO, n * 24));
+        HIP_TRY(hipMemcpy(dV, v, n * 24, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(probeUnitKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dV, dO, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(out, dO, n * 24, hipMemcpyDeviceToHost));
+        return GRAFT_OK;
+    };
+    const int rc = run();
+    (void)hipFree(dV); (void)hipFree(dO);  // on every path
     return rc;
 }
 

@@ -188,6 +188,32 @@ def test_device_sqrt_and_divide_are_correctly_rounded(gpu):
     assert np.all(np.isnan(out[np.isnan(want)]))
 
 
+def test_device_unit_vector_equals_sqrt_and_divide(gpu):
+    """vecUnit as the kernels' hot stages evaluate it (square root without rescaling, one reciprocal shared by the three
+    quotients) against numpy's sqrt and divide with the reference's order of operations (vector.c:57-82), bit for bit:
+    ordinary vectors, tiny and huge ones, zero components, the zero vector."""
+    from raytracing_amd._lib import c_double_p, check, lib
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    v = np.concatenate([rng.uniform(-2000, 2000, (n // 4, 3)), rng.standard_normal((n // 4, 3)),
+                        rng.standard_normal((n // 4, 3)) * 10.0 ** rng.uniform(-300, 300, (n // 4, 1)),
+                        rng.standard_normal((n // 4, 3)) * 10.0 ** rng.uniform(-160, 160, (n // 4, 3))])
+    v[:6] = [[0, 0, 0], [1, 0, 0], [0, -3, 4], [1e-200, 1e-200, 0], [1e200, -1e200, 1e199], [5e-324, 0, 0]]
+    v[np.arange(6, 2006), rng.integers(0, 3, 2000)] = 0.0
+    v = np.ascontiguousarray(v)
+    out = np.zeros_like(v)
+    check(lib.graftProbeUnit(v.ctypes.data_as(c_double_p), out.ctypes.data_as(c_double_p), n))
+    with np.errstate(all="ignore"):
+        acc = 0.0 + v[:, 0] * v[:, 0]
+        acc = acc + v[:, 1] * v[:, 1]
+        acc = acc + v[:, 2] * v[:, 2]
+        mag = np.sqrt(acc)
+        want = np.where((mag > 0)[:, None], v / mag[:, None], 0.0)
+    ok = ~np.isnan(want)
+    assert np.array_equal(out.view(np.uint64)[ok], want.view(np.uint64)[ok])
+    assert np.all(np.isnan(out[~ok]))
+
+
 def test_full_size_rows_match_oracle(gpu):
     """At the full frame sizes of the measured workloads the oracle cannot trace the whole frame in seconds:
     compare evenly spaced whole rows (first and last included) bit-for-bit instead."""
