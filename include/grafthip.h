@@ -258,6 +258,9 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
  * row first), quantising with q(v) = (uint8)(min(max(v,0),1)*255 + 0.5) where the format is not already 8 bit.
  * For headless runs: the reference can only show its frame in a window (000pixel.h:31-39). */
 GRAFT_API int graftWritePPM(const char *path, const void *frameHost, int format, int nCols, int nRows);
+/* The same frame as a PNG (8-bit RGB, uncompressed deflate blocks: no library needed); frames whose scanlines exceed
+ * 2 GiB are refused with GRAFT_ERR_UNSUPPORTED. */
+GRAFT_API int graftWritePNG(const char *path, const void *frameHost, int format, int nCols, int nRows);
 
 /* Bytes per pixel of a GRAFT_OUT_* format, 0 if unknown. */
 GRAFT_API size_t graftPixelBytes(int format);

@@ -6,10 +6,10 @@ C-ABI library that holds the hand-written HIP kernels (csrc/grafthip.hip, includ
 from . import _lib  # noqa: F401  (raises if the HIP library has not been built)
 from .tracer import (ANTIALIASING_OFF, ANTIALIASING_ON, ORTHOGRAPHIC, PERSPECTIVE, Job, Light, RayTracer, Shape,
                      device_count, frame_pieces, frame_plan, get_diagnostic, multi_stats, init, init_devices, lightInit, lightSetAvoid, planeInit, planeMalloc, sphereInit,
-                     sphereMalloc, set_diagnostic, write_ppm)
+                     sphereMalloc, set_diagnostic, write_png, write_ppm)
 from ._lib import GRAFT_OUT_F32_RGBA, GRAFT_OUT_F64_RGB, GRAFT_OUT_U8_RGBA, GraftError
 
 __all__ = ["RayTracer", "Shape", "Light", "Job", "init", "device_count", "sphereMalloc", "sphereInit",
            "planeMalloc", "planeInit", "lightInit", "lightSetAvoid", "ORTHOGRAPHIC", "PERSPECTIVE",
            "ANTIALIASING_OFF", "ANTIALIASING_ON", "GRAFT_OUT_F64_RGB", "GRAFT_OUT_F32_RGBA", "GRAFT_OUT_U8_RGBA",
-           "GraftError", "write_ppm", "set_diagnostic", "get_diagnostic", "init_devices", "frame_pieces", "frame_plan", "multi_stats"]
+           "GraftError", "write_ppm", "write_png", "set_diagnostic", "get_diagnostic", "init_devices", "frame_pieces", "frame_plan", "multi_stats"]

@@ -97,6 +97,7 @@ if hasattr(lib, "graftFramePlan"):  # (an older build loaded through GRAFT_LIB f
 lib.graftRenderFrameMulti.argtypes = [ctypes.POINTER(GraftScene), ctypes.POINTER(GraftView), ctypes.c_int, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 lib.graftWritePPM.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+lib.graftWritePNG.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 lib.graftDiagnosticSet.argtypes = [ctypes.c_int, ctypes.c_int]
 lib.graftDiagnosticGet.argtypes = [ctypes.c_int]
 lib.graftHostAlloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]

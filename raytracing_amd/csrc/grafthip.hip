@@ -1183,6 +1183,19 @@ GRAFT_API int graftDiagnosticGet(int which) {
     }
 }
 
+// row iy of a host frame as 8-bit RGB triples (the quantiser of the RGB bar; NaN -> 0)
+static void quantiseRow(const void *frameHost, int format, int nCols, int iy, unsigned char *row) {
+    auto q = [](double v) { return (unsigned char)((v < 0 ? 0 : (v > 1 ? 1 : (v == v ? v : 0))) * 255 + 0.5); };
+    for (int ix = 0; ix < nCols; ++ix) {
+        const size_t p = (size_t)iy * nCols + ix;
+        for (int c = 0; c < 3; ++c) {
+            if (format == GRAFT_OUT_F64_RGB) row[3 * ix + c] = q(((const double *)frameHost)[3 * p + c]);
+            else if (format == GRAFT_OUT_F32_RGBA) row[3 * ix + c] = q(((const float *)frameHost)[4 * p + c]);
+            else row[3 * ix + c] = ((const unsigned char *)frameHost)[4 * p + c];
+        }
+    }
+}
+
 GRAFT_API int graftWritePPM(const char *path, const void *frameHost, int format, int nCols, int nRows) {
     if (!path || !frameHost || nCols <= 0 || nRows <= 0 || graftPixelBytes(format) == 0)
         return fail(GRAFT_ERR_ARG, "graftWritePPM: bad argument");
@@ -1190,22 +1203,81 @@ GRAFT_API int graftWritePPM(const char *path, const void *frameHost, int format,
     if (!f) return fail(GRAFT_ERR_ARG, "graftWritePPM: cannot open %s", path);
     fprintf(f, "P6\n%d %d\n255\n", nCols, nRows);
     std::vector<unsigned char> row(3 * (size_t)nCols);
-    auto q = [](double v) { return (unsigned char)((v < 0 ? 0 : (v > 1 ? 1 : (v == v ? v : 0))) * 255 + 0.5); };
     for (int iy = nRows - 1; iy >= 0; --iy) {
-        for (int ix = 0; ix < nCols; ++ix) {
-            const size_t p = (size_t)iy * nCols + ix;
-            for (int c = 0; c < 3; ++c) {
-                if (format == GRAFT_OUT_F64_RGB) row[3 * ix + c] = q(((const double *)frameHost)[3 * p + c]);
-                else if (format == GRAFT_OUT_F32_RGBA) row[3 * ix + c] = q(((const float *)frameHost)[4 * p + c]);
-                else row[3 * ix + c] = ((const unsigned char *)frameHost)[4 * p + c];
-            }
-        }
+        quantiseRow(frameHost, format, nCols, iy, row.data());
         if (fwrite(row.data(), 1, row.size(), f) != row.size()) {
             fclose(f);
             return fail(GRAFT_ERR_ARG, "graftWritePPM: short write to %s", path);
         }
     }
     fclose(f);
+    return GRAFT_OK;
+}
+
+// PNG: 8-bit RGB, no interlace, every scanline with filter type 0, the zlib stream made of STORED deflate blocks (no
+// compression, no dependency): signature, IHDR, one IDAT, IEND; CRC-32 per chunk, Adler-32 over the scanlines.
+GRAFT_API int graftWritePNG(const char *path, const void *frameHost, int format, int nCols, int nRows) {
+    if (!path || !frameHost || nCols <= 0 || nRows <= 0 || graftPixelBytes(format) == 0)
+        return fail(GRAFT_ERR_ARG, "graftWritePNG: bad argument");
+    const unsigned long long lineBytes = 1ull + 3ull * (unsigned long long)nCols, raw = lineBytes * (unsigned long long)nRows;
+    const unsigned long long blocks = (raw + 65534) / 65535, idat = 2 + raw + 5 * blocks + 4;
+    if (idat > 0x7fffffffull) return fail(GRAFT_ERR_UNSUPPORTED, "graftWritePNG: a %d x %d frame does not fit one IDAT chunk (use graftWritePPM)", nCols, nRows);
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(GRAFT_ERR_ARG, "graftWritePNG: cannot open %s", path);
+    static unsigned table[256];
+    if (!table[1])
+        for (unsigned n = 0; n < 256; ++n) {
+            unsigned c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            table[n] = c;
+        }
+    bool ok = true;
+    unsigned crc = 0;
+    auto put = [&](const unsigned char *b, size_t n) {  // bytes of the chunk being written (type and data go into its CRC)
+        for (size_t i = 0; i < n; ++i) crc = table[(crc ^ b[i]) & 0xff] ^ (crc >> 8);
+        ok = ok && fwrite(b, 1, n, f) == n;
+    };
+    auto put32 = [&](unsigned v) { const unsigned char b[4] = {(unsigned char)(v >> 24), (unsigned char)(v >> 16), (unsigned char)(v >> 8), (unsigned char)v}; put(b, 4); };
+    auto begin = [&](unsigned length, const char *type) { put32(length); crc = 0xffffffffu; put((const unsigned char *)type, 4); };
+    auto end = [&]() { const unsigned c = crc ^ 0xffffffffu; put32(c); };
+    const unsigned char signature[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    put(signature, 8);
+    begin(13, "IHDR");
+    put32((unsigned)nCols); put32((unsigned)nRows);
+    const unsigned char header[5] = {8, 2, 0, 0, 0};  // bit depth 8, colour type 2 (RGB), deflate, filter method 0, no interlace
+    put(header, 5);
+    end();
+    begin((unsigned)idat, "IDAT");
+    const unsigned char zlibHeader[2] = {0x78, 0x01};
+    put(zlibHeader, 2);
+    std::vector<unsigned char> line((size_t)lineBytes);
+    unsigned a = 1, b = 0;  // Adler-32
+    unsigned long long sent = 0;  // bytes of scanline data written so far
+    for (int iy = nRows - 1; iy >= 0 && ok; --iy) {  // top row first
+        line[0] = 0;
+        quantiseRow(frameHost, format, nCols, iy, line.data() + 1);
+        for (size_t i = 0; i < line.size(); ++i) { a = (a + line[i]) % 65521u; b = (b + a) % 65521u; }
+        size_t at = 0;
+        while (at < line.size()) {
+            if (sent % 65535 == 0) {  // a new stored block starts here
+                const unsigned long long left = raw - sent;
+                const unsigned len = (unsigned)(left < 65535 ? left : 65535);
+                const unsigned char head[5] = {(unsigned char)(left <= 65535 ? 1 : 0), (unsigned char)len, (unsigned char)(len >> 8),
+                                               (unsigned char)~len, (unsigned char)(~len >> 8)};
+                put(head, 5);
+            }
+            const size_t room = (size_t)(65535 - sent % 65535), n = line.size() - at < room ? line.size() - at : room;
+            put(line.data() + at, n);
+            at += n;
+            sent += n;
+        }
+    }
+    put32((b << 16) | a);
+    end();
+    begin(0, "IEND");
+    end();
+    ok = fclose(f) == 0 && ok;
+    if (!ok) return fail(GRAFT_ERR_ARG, "graftWritePNG: short write to %s", path);
     return GRAFT_OK;
 }
 

@@ -96,6 +96,12 @@ def write_ppm(path, frame, fmt=GRAFT_OUT_F64_RGB):
     check(lib.graftWritePPM(str(path).encode(), a.ctypes.data_as(ctypes.c_void_p), int(fmt), a.shape[1], a.shape[0]))
 
 
+def write_png(path, frame, fmt=GRAFT_OUT_F64_RGB):
+    """Save a host frame ([rows][cols][channels], row 0 at the bottom as pixSetRGB counts) as an 8-bit RGB PNG."""
+    a = np.ascontiguousarray(frame)
+    check(lib.graftWritePNG(str(path).encode(), a.ctypes.data_as(ctypes.c_void_p), int(fmt), a.shape[1], a.shape[0]))
+
+
 # ---- shapes.c / light.c ---------------------------------------------------------------------------------
 
 class Shape:

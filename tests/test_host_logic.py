@@ -90,6 +90,30 @@ def test_write_ppm(tmp_path):
             assert np.array_equal(got, want)
 
 
+def test_write_png(tmp_path):
+    """Headless output as PNG: decoded by an independent reader (PIL) it is the PPM's picture; a frame whose scanlines
+    span several stored deflate blocks included."""
+    from PIL import Image
+    from raytracing_amd import GRAFT_OUT_F32_RGBA, GRAFT_OUT_F64_RGB, write_png
+    rng = np.random.default_rng(5)
+    for shape in ((5, 7), (1, 1), (300, 211)):   # 300 x 211: 190 200 bytes of scanlines = three stored blocks
+        f64 = rng.uniform(-0.2, 1.3, shape + (3,))
+        f64[0, 0] = [np.nan, 0.5, 1.0]
+        want = (np.clip(np.nan_to_num(f64), 0, 1) * 255 + 0.5).astype(np.uint8)[::-1]
+        path = tmp_path / "f.png"
+        write_png(path, f64, GRAFT_OUT_F64_RGB)
+        with Image.open(path) as im:
+            assert im.mode == "RGB" and im.size == (shape[1], shape[0])
+            assert np.array_equal(np.asarray(im), want)
+        f32 = np.concatenate([f64, np.ones(shape + (1,))], 2).astype(np.float32)
+        write_png(path, f32, GRAFT_OUT_F32_RGBA)
+        with Image.open(path) as im:
+            want32 = (np.clip(np.nan_to_num(f32[..., :3].astype(np.float64)), 0, 1) * 255 + 0.5).astype(np.uint8)[::-1]
+            assert np.array_equal(np.asarray(im), want32)
+    with pytest.raises(Exception):
+        write_png(tmp_path / "no_such_dir" / "f.png", f64, GRAFT_OUT_F64_RGB)
+
+
 @pytest.mark.parametrize("rows,world,chunks", [(16384, 8, 8), (8192, 4, 11), (4096, 2, 16), (512, 3, 5), (100, 8, 8),
                                                (8, 8, 4), (1, 2, 3), (72, 5, 1), (4097, 7, 9)])
 def test_c_piece_list_equals_the_python_one(rows, world, chunks):
