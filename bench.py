@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 import raytracing_amd  # noqa: E402
 from raytracing_amd import scenes  # noqa: E402
 from raytracing_amd.distributed import local_rows, trace_and_gather  # noqa: E402
-from raytracing_amd.tracer import GRAFT_OUT_F32_RGBA, GRAFT_OUT_F64_RGB  # noqa: E402
+from raytracing_amd.tracer import GRAFT_OUT_F32_RGBA, GRAFT_OUT_F64_RGB, GRAFT_OUT_U8_RGBA  # noqa: E402
 
 FLOP_PER_TEST = 17            # FP64 flops of one ray-sphere test on the miss path (shapes.c:52-54)
 PEAK_FP64_VALU = 78.6         # TFLOP/s, FMA counted as 2
@@ -82,7 +82,11 @@ def cpu_baseline(rt, gpu_band, row0, n_rows, cores, budget_rows):
         rays += o["counters"][0]
         if gpu_band is not None:
             mine = gpu_band[r - row0, :, :3].cpu().numpy()
-            exact = exact and np.array_equal(mine, o["rgb"][0].astype(np.float32))
+            if mine.dtype == np.uint8:  # RGBA8 frame: the quantiser of the RGB bar, q(v) = (uint8)(min(max(v,0),1)*255 + 0.5)
+                want = (np.clip(np.nan_to_num(o["rgb"][0]), 0, 1) * 255 + 0.5).astype(np.uint8)
+            else:
+                want = o["rgb"][0].astype(np.float32)
+            exact = exact and np.array_equal(mine, want)
     # the reference's own execution model is one thread: the same port on one core, over a few of the sampled rows
     few = picks[::max(1, len(picks) // 4)][:4]
     rays1, secs1 = 0, 0.0
@@ -345,6 +349,9 @@ def main():
     ap.add_argument("--no-host-frame", action="store_true")
     ap.add_argument("--chunks", type=int, default=None,
                     help="pieces per GPU in the trace/gather pipeline (N > 1); default 8 * sqrt(8 / N)")
+    ap.add_argument("--format", choices=("f32", "u8"), default="f32",
+                    help="frame in HBM: float4 RGBA (16 bytes per pixel, the default) or RGBA8 (4 bytes: a quarter of the "
+                         "bytes the gather moves at N > 1)")
     ap.add_argument("--reserve-cus", type=int, default=None,
                     help="compute units every trace leaves free (default: 4 at N > 1, where RCCL's transfer kernels "
                          "run beside the traces; 0 on one GPU)")
@@ -376,11 +383,12 @@ def main():
     job = rt.create_job()
     W, H = job.nCols, job.nRows
     row0, n_rows = 0, H
+    fmt, frame_dtype = (GRAFT_OUT_U8_RGBA, torch.uint8) if args.format == "u8" else (GRAFT_OUT_F32_RGBA, torch.float32)
     if rank == 0:  # rank 0 owns the assembled frame and traces straight into its own rows of it
-        frame = band = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+        frame = band = torch.empty((H, W, 4), dtype=frame_dtype, device=dev)
     else:          # the other ranks trace their pieces into a buffer of their own and send them to rank 0
         frame = None
-        band = torch.empty((local_rows(H, world, rank, args.chunks), W, 4), dtype=torch.float32, device=dev)
+        band = torch.empty((local_rows(H, world, rank, args.chunks), W, 4), dtype=frame_dtype, device=dev)
     counters = torch.zeros(4, dtype=torch.int64, device=dev)  # one GraftCounters
     # a real (non-null) stream: kernels, events and the RCCL transfers of the gather are all ordered on it
     torch_stream = torch.cuda.Stream(device=dev)
@@ -389,8 +397,7 @@ def main():
 
     def step(count=False, stats=None):
         def trace(first, rows, piece):
-            job.trace(first, rows, GRAFT_OUT_F32_RGBA, piece.data_ptr(), None, counters.data_ptr() if count else None,
-                      stream)
+            job.trace(first, rows, fmt, piece.data_ptr(), None, counters.data_ptr() if count else None, stream)
         trace_and_gather(trace, band, frame, H, world, rank, args.chunks, stats=stats)
 
     def fence():
@@ -418,7 +425,7 @@ def main():
     for k in range(args.steps):
         if world == 1:  # one launch per frame: its HIP-event time is the kernel time of the roofline
             ev[k][0].record()
-            job.trace(row0, n_rows, GRAFT_OUT_F32_RGBA, band.data_ptr(), None, None, stream)
+            job.trace(row0, n_rows, fmt, band.data_ptr(), None, None, stream)
             ev[k][1].record()
         else:           # pieces of the band are traced and shipped to rank 0 in a pipeline
             ev[k][0].record()
@@ -446,7 +453,8 @@ def main():
             "metric": "Mrays/s", "value": rays / (elapsed / args.steps) / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic", "config": {"workload": desc, "frame": [W, H], "output": "float4 RGBA in HBM",
+            "data": "synthetic", "config": {"workload": desc, "frame": [W, H],
+                                            "output": "RGBA8 in HBM" if args.format == "u8" else "float4 RGBA in HBM",
                                             "screen_level": job.screen_level(),
                                             "rays_counted": "closest-hit queries the kernel made (%.4g per frame); the "
                                                             "reference makes %.4g for the same frame, see `reference`"
@@ -479,12 +487,12 @@ def main():
                 out["ray_imbalance"] = max(p["rays"] for p in per_rank) / (rays / world)
             torch.cuda.synchronize()
             # the assembled frame against rank 0's own trace of 64 tile rows spread over all pieces
-            check = torch.empty((8, W, 4), dtype=torch.float32, device=dev)
+            check = torch.empty((8, W, 4), dtype=frame_dtype, device=dev)
             same, checked = True, 0
             for i in range(64):
                 r = min(int((i + 0.5) * H / 64) // 8 * 8, max(H - 8, 0))
                 n = min(8, H - r)
-                job.trace(r, n, GRAFT_OUT_F32_RGBA, check.data_ptr(), None, None, stream)
+                job.trace(r, n, fmt, check.data_ptr(), None, None, stream)
                 torch.cuda.synchronize()
                 same = same and bool(torch.equal(check[:n], frame[r:r + n]))
                 checked += 1

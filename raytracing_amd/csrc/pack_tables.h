@@ -3,13 +3,44 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <thread>
 #include <utility>
 #include <vector>
 
 #include "trace_types.h"
 
 namespace graft {
+
+// The tables of a large scene are built on several host threads: body(begin, end) runs over contiguous ranges of
+// [0, n), at least `grain` items each, on at most hostThreads() threads (the calling thread takes the first range).  What
+// a body computes for an item must not depend on the split: the tables are the same whatever the thread count.
+inline int hostThreads() {
+    static const int threads = [] {
+        int t = (int)std::thread::hardware_concurrency();
+        if (const char *e = getenv("GRAFT_HOST_THREADS"))
+            if (atoi(e) > 0) t = atoi(e);
+        return std::max(1, std::min(t, 16));
+    }();
+    return threads;
+}
+
+template <class Body>
+inline void parallelRanges(int n, int grain, Body body) {
+    const int t = std::min(hostThreads(), n / std::max(1, grain));
+    if (t <= 1) {
+        body(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)t - 1);
+    for (int i = 1; i < t; ++i)
+        pool.emplace_back([&body, n, t, i] { body((int)((long long)n * i / t), (int)((long long)n * (i + 1) / t)); });
+    body(0, (int)((long long)n / t));
+    for (std::thread &th : pool) th.join();
+}
 
 // Single-precision screen table.  Per sphere: (float)cx, (float)cy, (float)cz and rho >= r*r + the sphere's share
 // of the screen's worst-case error (64 u |c|_1^2 + 2.2 u rho, u = 2^-24), rounded up; centre 0 and rho = +inf
@@ -286,23 +317,29 @@ inline void packConeTable(const std::vector<double> &sph, const double apex[3], 
         return -kappa2(theta, nearest);
     };
     const int nGroups = (n + kGroup - 1) / kGroup;
-    for (int gI = 0; gI < nGroups; ++gI) {
-        const int first = gI * kGroup, last = std::min(n, first + kGroup);
-        double a[3];
-        const float w = enclose(first, last, a);
-        T.group(gI, (float)a[0], (float)a[1], (float)a[2], w);
-        for (int m = first; m < last; ++m) {
-            const int k = order[m];
-            T.member(gI, m - first, k, (float)dir[3 * (size_t)k], (float)dir[3 * (size_t)k + 1],
-                     (float)dir[3 * (size_t)k + 2], -kappa2(alpha[k], dist[k]));
+    // (every group and every third-level entry writes floats of its own: ranges of them go to different threads)
+    parallelRanges(nGroups, 16, [&](int gBegin, int gEnd) {
+        for (int gI = gBegin; gI < gEnd; ++gI) {
+            const int first = gI * kGroup, last = std::min(n, first + kGroup);
+            double a[3];
+            const float w = enclose(first, last, a);
+            T.group(gI, (float)a[0], (float)a[1], (float)a[2], w);
+            for (int m = first; m < last; ++m) {
+                const int k = order[m];
+                T.member(gI, m - first, k, (float)dir[3 * (size_t)k], (float)dir[3 * (size_t)k + 1],
+                         (float)dir[3 * (size_t)k + 2], -kappa2(alpha[k], dist[k]));
+            }
         }
-    }
-    for (int sI = 0; sI * kSuper < nGroups; ++sI) {
-        const int first = sI * kSuper * kGroup, last = std::min(n, first + kSuper * kGroup);
-        double a[3];
-        const float w = enclose(first, last, a);
-        T.super(sI, (float)a[0], (float)a[1], (float)a[2], w);
-    }
+    });
+    const int nSupers = (nGroups + kSuper - 1) / kSuper;
+    parallelRanges(nSupers, 2, [&](int sBegin, int sEnd) {
+        for (int sI = sBegin; sI < sEnd; ++sI) {
+            const int first = sI * kSuper * kGroup, last = std::min(n, first + kSuper * kGroup);
+            double a[3];
+            const float w = enclose(first, last, a);
+            T.super(sI, (float)a[0], (float)a[1], (float)a[2], w);
+        }
+    });
 }
 
 // Uniform grid over the spheres for rays that pass through no fixed point (mirror rays and the shadow rays of their
@@ -476,32 +513,42 @@ inline bool packLightLists(const std::vector<double> &sph, const double light[3]
             if (B < kWide) { wideB[k] = 0; cosB[k] = cos(B); sinB[k] = sin(B); }
         }
     }
+    // the list of every sphere k on its own (ranges of k on different threads), then all of them into the pool in order
+    std::vector<std::vector<unsigned short>> lists((size_t)n);
+    std::vector<unsigned char> listsAll((size_t)n, 0);
+    std::atomic<bool> tooLong(false);
+    parallelRanges(n, 128, [&](int kBegin, int kEnd) {
+        for (int k = kBegin; k < kEnd && !tooLong.load(std::memory_order_relaxed); ++k) {
+            std::vector<unsigned short> &list = lists[(size_t)k];
+            bool all = wideB[k] != 0 && !avoidRow;  // (with an avoid list the list of everything else is written out)
+            const double *uk = &dir[3 * (size_t)k];
+            const double reach = (dist[k] + rad[k] + grow[k]) * (1 + 1e-12);
+            const bool everything = wideB[k] != 0;  // no bound on where its shadow rays go: every sphere is a candidate
+            for (int j = 0; j < n && !all; ++j) {
+                if (j == k || (avoidRow && avoidRow[j])) continue;
+                if (!wideA[j] && !everything) {
+                    const double *uj = &dir[3 * (size_t)j];
+                    const double c = uj[0] * uk[0] + uj[1] * uk[1] + uj[2] * uk[2];
+                    // cos(A_j + B_k); both angles are below kWide, so the sum is below pi and the cosine decreases
+                    if (c < cosA[j] * cosB[k] - sinA[j] * sinB[k] - 1e-12) continue;
+                    // wholly behind sphere k as seen from the light (and within a right angle of it, see above)
+                    if (dist[j] - rad[j] > reach && c > 0.5 && cosA[j] > 0.9 && cosB[k] > 0.9) continue;
+                }
+                list.push_back((unsigned short)j);
+                if (list.size() >= kListAll) {
+                    if (avoidRow) tooLong.store(true, std::memory_order_relaxed);  // (too long to write out, and the list of all spheres would undo the avoid list)
+                    all = true;
+                }
+            }
+            listsAll[(size_t)k] = all ? 1 : 0;
+        }
+    });
+    if (tooLong.load()) return false;
     T.index.assign(n, 0);
     T.pool.clear();
-    std::vector<unsigned short> list;
     for (int k = 0; k < n; ++k) {
-        list.clear();
-        bool all = wideB[k] != 0 && !avoidRow;  // (with an avoid list the list of everything else is written out)
-        const double *uk = &dir[3 * (size_t)k];
-        const double reach = (dist[k] + rad[k] + grow[k]) * (1 + 1e-12);
-        const bool everything = wideB[k] != 0;  // no bound on where its shadow rays go: every sphere is a candidate
-        for (int j = 0; j < n && !all; ++j) {
-            if (j == k || (avoidRow && avoidRow[j])) continue;
-            if (!wideA[j] && !everything) {
-                const double *uj = &dir[3 * (size_t)j];
-                const double c = uj[0] * uk[0] + uj[1] * uk[1] + uj[2] * uk[2];
-                // cos(A_j + B_k); both angles are below kWide, so the sum is below pi and the cosine decreases
-                if (c < cosA[j] * cosB[k] - sinA[j] * sinB[k] - 1e-12) continue;
-                // wholly behind sphere k as seen from the light (and within a right angle of it, see above)
-                if (dist[j] - rad[j] > reach && c > 0.5 && cosA[j] > 0.9 && cosB[k] > 0.9) continue;
-            }
-            list.push_back((unsigned short)j);
-            if (list.size() >= kListAll) {
-                if (avoidRow) return false;  // (too long to write out, and the list of all spheres would undo the avoid list)
-                all = true;
-            }
-        }
-        if (all) {
+        const std::vector<unsigned short> &list = lists[(size_t)k];
+        if (listsAll[(size_t)k]) {
             T.index[k] = kListAll << 20;
         } else {
             if ((T.pool.size() + list.size()) / 4 + 1 >= (1u << 20)) return false;

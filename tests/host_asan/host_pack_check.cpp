@@ -186,6 +186,7 @@ static void checkStructure(const PackedJob &J, const Scene &S, const char *what)
 static void wellFormed(int scenes) {
     TableCache cache;
     int levels[kMaxScreen + 1] = {0};
+    unsigned long long imagesFnv = 1469598103934665603ull;  // over every packed image: the same whatever the thread count
     for (int seed = 0; seed < scenes; ++seed) {
         Scene S = randomScene((uint64_t)seed);
         for (int cap = 0; cap <= kMaxScreen; ++cap) {
@@ -200,6 +201,7 @@ static void wellFormed(int scenes) {
             if (rc != GRAFT_OK) continue;
             EXPECT(J.screen <= cap, "seed %d: level %d above cap %d", seed, J.screen, cap);
             levels[J.screen]++;
+            for (unsigned char b : J.image) imagesFnv = (imagesFnv ^ b) * 1099511628211ull;
             char what[64];
             snprintf(what, sizeof what, "seed %d cap %d level %d", seed, cap, J.screen);
             checkStructure(J, S, what);
@@ -215,6 +217,7 @@ static void wellFormed(int scenes) {
     printf("well-formed scenes: %d x %d caps; jobs per level:", scenes, kMaxScreen + 1);
     for (int l = 0; l <= kMaxScreen; ++l) printf(" %d:%d", l, levels[l]);
     printf("\n");
+    printf("images fnv %016llx (%d host threads)\n", imagesFnv, hostThreads());
     for (int l = 0; l <= kMaxScreen; ++l)
         if (scenes >= 200) EXPECT(levels[l] > 0, "no job reached level %d", l);
 }
