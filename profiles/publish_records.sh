@@ -10,6 +10,8 @@ for wl in cfg3_level0:cfg3:0 cfg3:cfg3:7 cfg5:cfg5:7 cfg4:cfg4:7; do
   dir=${wl%%:*}; rest=${wl#*:}; name=${rest%%:*}; cap=${rest#*:}
   src=gpurun_out/pmc_$TAG/$dir
   [ -d "$src" ] || continue
+  # (gpurun merges what a run wrote into what is already here: a second collection under the same tag leaves two sets)
+  if [ "$(ls $src/trace/*/*kernel_stats.csv | wc -l)" != 1 ]; then echo "$src holds more than one collection: remove it and collect again, or use another tag" >&2; exit 1; fi
   python profiles/summarize_pmc.py $src $name $cap > profiles/pmc_$dir.json
   cp $src/trace/*/*kernel_stats.csv profiles/${TAG}_${dir}_kernel_stats.csv
   python - "$src" > profiles/${TAG}_${dir}_trace_kernel_rows.csv <<'PY'

@@ -33,11 +33,12 @@ def test_record_matches_the_sources_and_gives_fractions(path):
     # SIMD -- and can come out a few percent above 1 on a launch whose engines finish at different times)
     assert 0 < roof["valu_busy"] <= 1.1 and 0 < roof["lane_utilisation"] <= 1
     # The trace pass runs the bench with warm-up steps; its timed steps are the last launches in the kernel trace.  Their
-    # average and the bench's own HIP-event time for the same steps agree to 3 %.
+    # average and the bench's own HIP-event time for the same steps agree to 3 % (or 15 microseconds on launches of a
+    # fraction of a millisecond: the events also bracket the memset of the ticket counters and the gap before the launch).
     trace, under = rec["kernel_trace"], rec["bench_under_trace"]
     assert trace["warm_calls"] == under["steps"] >= 10
     warm_ms = trace["warm_average_ns"] / 1e6
-    assert abs(warm_ms - under["kernel_ms"]) <= 0.03 * warm_ms, (warm_ms, under["kernel_ms"])
+    assert abs(warm_ms - under["kernel_ms"]) <= max(0.03 * warm_ms, 0.015), (warm_ms, under["kernel_ms"])
     assert abs(rec["derived"]["kernel_ms"] - warm_ms) < 1e-9
 
 
