@@ -285,6 +285,29 @@ def test_lists_supersampled_rotated_zoomed(gpu):
     check_all_levels(rt, levels=(0, 6))
 
 
+def test_lists_shared_by_the_tiles_of_a_ticket(gpu):
+    """Launches of fewer than four samples per pixel draw tickets of several 8x8 tiles, and the tiles of a ticket that lie
+    in one row of tiles share one tile list (built for the rectangle they cover).  Frames whose width is no multiple of
+    the tile, with tickets of 3, 5 and 16 tiles forced -- tickets that straddle rows of tiles, tickets longer than a
+    row --, one sample per pixel and supersampling with one pass; with mirrors (level 7, a list per tile) as well."""
+    old = get_diagnostic("tiles_per_ticket")
+    try:
+        for per_ticket in (3, 5, 16):
+            set_diagnostic("tiles_per_ticket", per_ticket)
+            rt = scene(70 + per_ticket, 120, size=(100, 44), radius=(4.0, 25.0))
+            check_all_levels(rt, levels=(0, 7))          # mirrors: level 7
+            check_all_levels(matte(rt), levels=(0, 6, 7))
+            rt.aliasing, rt.numPasses = ANTIALIASING_ON, 1
+            check_all_levels(rt, levels=(0, 6))
+            rt.aliasing, rt.numPasses = ANTIALIASING_ON, 2   # four samples: a list per tile, whatever the ticket
+            check_all_levels(rt, levels=(0, 6))
+        set_diagnostic("tiles_per_ticket", 4)
+        rt = matte(scene(79, 200, size=(13, 90), radius=(3.0, 12.0)))   # two tiles per row: every ticket spans rows
+        check_all_levels(rt, levels=(0, 6, 7))
+    finally:
+        set_diagnostic("tiles_per_ticket", old)
+
+
 def test_lists_lights_and_camera_inside_or_on_spheres(gpu):
     """The camera inside a sphere: that sphere is on every tile's list.  A light inside or on a sphere: that sphere is
     on every occluder list of the light, and a shadow ray that starts on it may meet any sphere."""
