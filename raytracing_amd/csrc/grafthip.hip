@@ -349,27 +349,28 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 rayReflects = 1;  // launchRays passes shouldReflect = 1, mainTracing.c:391
                 mode = M_RADIANCE;
             };
-            // Which lights may lie in front of the surface at the hit being shaded (bit i = light i)?  "Behind" only
-            // when the cosine the reference computes is below -1e-10 for certain, far from its rounding.  The loop is
-            // the same for all lanes, so the lights' positions come through scalar loads.  (Jobs whose colours and
-            // weights are not all finite -- there 0 * colour is not 0 --, small scenes and jobs with more than 31
-            // lights take every light to be in front.)
-            unsigned frontMask = ~0u;
+            // Which is the FIRST light that may lie in front of the surface at the hit being shaded?  "Behind" only when
+            // the cosine the reference computes is below -1e-10 for certain, far from its rounding.  The lights are gone
+            // through from light 0 until one is in front -- neighbouring pixels mostly stop at the same one --, their
+            // positions come through scalar loads.  (Jobs whose colours and weights are not all finite -- there
+            // 0 * colour is not 0 --, small scenes and jobs with more than 31 lights take every light to be in front.)
+            int firstFront = 0;
             auto findFront = [&]() {
-                frontMask = ~0u;
+                firstFront = 0;
                 if (!P.skipLightsBehind || P.numLights > 31) return;
                 const ConstDoubles LD = (ConstDoubles)(unsigned long long)P.lights;
                 const double nn = nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2];
-                frontMask = 0;
-                for (int i = 0; i < P.numLights; ++i) {
+                int i = 0;
+                for (; i < P.numLights; ++i) {
                     const double bx = LD[8 * i + 3] - loc[0], by2 = LD[8 * i + 4] - loc[1], bz = LD[8 * i + 5] - loc[2];
                     const double q = bx * nrm[0] + by2 * nrm[1] + bz * nrm[2];
                     const double bb = bx * bx + by2 * by2 + bz * bz;
-                    if (!(q < 0 && q * q > 1e-20 * (bb * nn))) frontMask |= 1u << i;
+                    if (!(q < 0 && q * q > 1e-20 * (bb * nn))) break;
                 }
+                firstFront = i;  // (numLights: every light lies behind the surface)
             };
             // may one of the lights 0 .. last shine on the hit?
-            auto mayShine = [&](int last) { return last >= 0 && (frontMask & (0xffffffffu >> (31 - min(last, 31)))) != 0; };
+            auto mayShine = [&](int last) { return last >= firstFront; };
             // The stages of a round do not start the lane's next ray themselves: they say which kind it is, and ONE
             // piece of code at the end of the round normalises its direction and sets its origin for all lanes
             // together.  (Lanes of a wave are in different stages: each stage doing this for itself would run the
