@@ -962,11 +962,13 @@ __device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles 
     T.ok = tt > 0 && tt < 1e300 && sinT < 0.5;  // (false for NaN)
     if (!T.ok) return -1;
 
-    // (group entries first, member entries behind them, in both tables)
+    // (the group entries are in LDS at either level; the member entries of the groups a tile opens come from global
+    // memory at level 7)
     const char *image = GLOBAL ? (const char *)P.geomF : (const char *)ldsGeom;
-    const float4v *groups = (const float4v *)(image + P.listGroupsOff);
-    const float4v *members = groups + P.listGroups;
-    const float *groupSin = (const float *)(image + P.listSinesOff), *memberSin = groupSin + P.listGroups;
+    const float4v *groups = (const float4v *)((const char *)ldsGeom + P.listGroupsOff);
+    const float *groupSin = (const float *)((const char *)ldsGeom + P.listSinesOff);
+    const float4v *members = (const float4v *)(image + P.listMembersOff);
+    const float *memberSin = (const float *)(image + P.listMemberSinesOff);
     const unsigned short *shapeOf = (const unsigned short *)(image + P.listShapeOff);
     const int gs = P.groupSize;
     int count = 0;

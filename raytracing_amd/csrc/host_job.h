@@ -194,14 +194,17 @@ inline bool packLists(TableCache &cache, const std::vector<double> &sph, const G
     const size_t oAos = 0, oExact = up(oAos + 16 * n, 32), afterExact = inLds ? oExact + 32 * n : oAos + 16 * n;
     const size_t oCells = up(afterExact, 16), oRefs = oCells + (wantGrid ? 4 * grid.cells.size() : 0);
     const size_t afterGrid = up(oRefs + (wantGrid ? 2 * grid.refs.size() : 0), 16);
-    const size_t oGroups = afterGrid, oSines = oGroups + 16 * entries, oShape = oSines + 4 * entries,
+    // (the camera table's group entries and their sines first: they are scanned for every tile list and are staged in
+    // LDS at level 7 as well; the member entries, read for the few groups a tile opens, follow)
+    const size_t oGroups = afterGrid, oSines = oGroups + 16 * G, afterGroups = up(oSines + 4 * G, 16);
+    const size_t oMembers = afterGroups, oMemberSines = oMembers + 16 * G * gs, oShape = oMemberSines + 4 * G * gs,
                  oIndex = up(oShape + 2 * G * gs, 4), oPool = up(oIndex + 4 * n * nL, 8);
     size_t poolEntries = up(n, 4);  // the list of all spheres comes first; every list starts at a multiple of 4 entries
     std::vector<size_t> base(nL);
     for (size_t i = 0; i < nL; ++i) { base[i] = poolEntries; poolEntries += lists[i]->pool.size(); }
     if (poolEntries / 4 >= (1u << 20)) return false;
     const size_t blob = up(oPool + 2 * poolEntries, 16);
-    staged = inLds ? blob : afterGrid;
+    staged = inLds ? blob : afterGroups;
     // in LDS behind the staged part: a tile list per wave and, where it fits, the waves' tables of sample scale factors
     // (launches of fewer than four samples per pixel run kernels that do not look at the table: launchTrace)
     const bool wantSamples = view->aliasing && view->numPasses >= 2 && view->numPasses <= kSampleTablePasses;
@@ -234,7 +237,7 @@ inline bool packLists(TableCache &cache, const std::vector<double> &sph, const G
     }
     // cone entries as {axis, cos A'} and sin A', from the table's -kappa2 = -(cos^2 A'): the cosine rounded down, the
     // sine up (either way the cone only widens); an entry that always passes gets cos = -2, one that never does +inf
-    auto coneEntries = [&](size_t first, size_t count, size_t at) {
+    auto coneEntries = [&](size_t first, size_t count, size_t oEntries, size_t oSin) {
         std::vector<float> plain;
         unpackEntries(cam.entries, first, count, plain);
         for (size_t e = 0; e < count; ++e) {
@@ -247,12 +250,12 @@ inline bool packLists(TableCache &cache, const std::vector<double> &sph, const G
                 sn = -floatBelow(-sqrt(1.0 - (double)c * (double)c) * (1.0 + 1e-12));
             }
             plain[4 * e + 3] = c;
-            memcpy(&img[oGroups + 16 * (at + e)], &plain[4 * e], 16);
-            memcpy(&img[oSines + 4 * (at + e)], &sn, 4);
+            memcpy(&img[oEntries + 16 * e], &plain[4 * e], 16);
+            memcpy(&img[oSin + 4 * e], &sn, 4);
         }
     };
-    coneEntries(0, G, 0);
-    coneEntries((size_t)cam.memberBase, G * gs, G);
+    coneEntries(0, G, oGroups, oSines);
+    coneEntries((size_t)cam.memberBase, G * gs, oMembers, oMemberSines);
     for (size_t m = 0; m < G * gs; ++m) {
         const unsigned short id = cam.memberShape[m] < 0 ? (unsigned short)0xffff : (unsigned short)cam.memberShape[m];
         memcpy(&img[oShape + 2 * m], &id, 2);
@@ -274,6 +277,7 @@ inline bool packLists(TableCache &cache, const std::vector<double> &sph, const G
     P.exactLdsOffset = (int)oExact;
     P.listGroups = (int)G;
     P.listGroupsOff = (int)oGroups; P.listSinesOff = (int)oSines; P.listShapeOff = (int)oShape;
+    P.listMembersOff = (int)oMembers; P.listMemberSinesOff = (int)oMemberSines;
     P.listIndexOff = (int)oIndex; P.listPoolOff = (int)oPool; P.listTileOff = (int)staged;
     if (wantGrid) {
         P.gridNx = grid.n[0]; P.gridNy = grid.n[1]; P.gridNz = grid.n[2];

@@ -133,16 +133,17 @@ struct TraceParams {
     const DevGrid *grid;
     // SCREEN == 6, 7 (candidate lists, closestHitLists): geomF holds an image laid out as {sphere screen table
     // [numSpheres] float4 | level 6: exact doubles at exactLdsOffset | level 7 with mirrors: the uniform grid's cells
-    // and entries (gridCellsOff, gridRefsOff; gridAosOff = the screen table) | camera cone table: listGroups
-    // group entries then listGroups * groupSize member entries, as {axis, cos} float4 at listGroupsOff and their sines
-    // (float) at listSinesOff, and the members' sphere numbers (16 bits) at listShapeOff | occluder-list index
+    // and entries (gridCellsOff, gridRefsOff; gridAosOff = the screen table) | camera cone table: listGroups group
+    // entries as {axis, cos} float4 at listGroupsOff and their sines (float) at listSinesOff; then the listGroups *
+    // groupSize member entries at listMembersOff, their sines at listMemberSinesOff and the members' sphere numbers
+    // (16 bits) at listShapeOff | occluder-list index
     // [numSpheres][numLights] | list pool (16-bit sphere numbers; the list of all spheres first) | one tile list of
     // kTileListCap entries per wave of the workgroup | with supersampling of at most kSampleTablePasses passes: per
     // wave 16 * numPasses doubles, the scale factors of the tile's columns and rows (sampleTableOff, else -1)}; byte
     // offsets from the start of the image.  Level 6 stages the whole image in LDS; level 7 its first ldsHeadFloats
-    // floats (everything in front of the camera table), reads the rest from global memory, and keeps the tile lists
-    // and sample tables in LDS behind the staged part
-    int listGroups, listGroupsOff, listSinesOff, listShapeOff, listIndexOff, listPoolOff, listTileOff, sampleTableOff;
+    // floats (everything up to and including the camera table's group entries, which every tile list scans), reads
+    // the rest from global memory, and keeps the tile lists and sample tables in LDS behind the staged part
+    int listGroups, listGroupsOff, listSinesOff, listMembersOff, listMemberSinesOff, listShapeOff, listIndexOff, listPoolOff, listTileOff, sampleTableOff;
     const int *memberShape;    // grouped screen: shape index of every member-table entry, -1 = padding
     const float *geomF;        // {cx, cy, cz, rho} per sphere in single precision, rho = inflated radius^2
     const double *geom;

@@ -150,8 +150,11 @@ static void checkStructure(const PackedJob &J, const Scene &S, const char *what)
         if (P.sampleTableOff >= 0)
             EXPECT((size_t)P.sampleTableOff + (size_t)(J.block / 64) * 128 * (size_t)P.numPasses <= J.ldsBytes && P.numPasses <= kSampleTablePasses,
                    "%s: sample tables", what);
-        const size_t entries = (size_t)P.listGroups * (1 + (size_t)P.groupSize);
-        EXPECT((size_t)P.listGroupsOff + 16 * entries <= bytes && (size_t)P.listSinesOff + 4 * entries <= bytes, "%s: camera table", what);
+        const size_t members = (size_t)P.listGroups * (size_t)P.groupSize;
+        EXPECT((size_t)P.listGroupsOff + 16 * (size_t)P.listGroups <= bytes && (size_t)P.listSinesOff + 4 * (size_t)P.listGroups <= bytes &&
+               (size_t)P.listMembersOff + 16 * members <= bytes && (size_t)P.listMemberSinesOff + 4 * members <= bytes, "%s: camera table", what);
+        // what the tile-list scan reads from LDS at either level lies inside the staged part
+        EXPECT((size_t)P.listSinesOff + 4 * (size_t)P.listGroups <= 4 * (size_t)P.ldsHeadFloats, "%s: camera groups staged", what);
         EXPECT((size_t)P.listShapeOff + 2 * (size_t)P.listGroups * P.groupSize <= bytes, "%s: member numbers", what);
         EXPECT((size_t)P.listIndexOff + 4 * n * nL <= bytes && (size_t)P.listPoolOff % 8 == 0, "%s: list index", what);
         if (J.screen == 6) EXPECT((size_t)P.exactLdsOffset + 32 * n <= staged, "%s: exact doubles", what);
