@@ -140,7 +140,10 @@ enum {
     GRAFT_DIAG_TILES_PER_TICKET = 2, /* 8x8 tiles a wave draws from the ticket counters at once: 0 = chosen per launch */
     GRAFT_DIAG_TABLE_BUILDS = 4,     /* read-only: screen tables built so far (shows what a re-render re-used) */
     GRAFT_DIAG_RESERVED_CUS = 5,     /* CUs a trace's persistent grid leaves free, 0..128; default 0 (graftRenderFrameMulti uses at least 4) */
-    GRAFT_DIAG_COPY_PIECE_KB = 6     /* graftRenderRows traces and copies a large frame in pieces of about this many KiB (at most 16 pieces); 0 = one piece; default 65536 */
+    GRAFT_DIAG_COPY_PIECE_KB = 6,    /* graftRenderRows traces and copies a large frame in pieces of about this many KiB (at most 16 pieces); 0 = one piece; default 65536 */
+    GRAFT_DIAG_EMULATED_DEVICES = 7  /* tests on a machine with too few GPUs: with n > 0 graftInitDevices may bind up to n devices, device d
+                                      * standing for GPU d mod (GPUs present) with streams, buffers and a job of its own; pieces then reach the
+                                      * root by device-to-device copies instead of RCCL; default 0 */
 };
 GRAFT_API int graftDiagnosticSet(int which, int value);
 GRAFT_API int graftDiagnosticGet(int which); /* -1 for an unknown setting */
@@ -237,13 +240,15 @@ GRAFT_API int graftRenderRowsNoAlloc(const GraftScene *scene, const GraftView *v
  * the tracing of the next round's pieces.
  *
  * graftInitDevices binds GPUs 0 .. nDevices-1 (GPU 0 is the root and the device of the single-GPU entry points; it is
- * graftInit(0) when nDevices is 1); if it fails, no multi-device frame can be started until a later call succeeds.
+ * graftInit(0) when nDevices is 1); if it fails, no multi-device frame can be started until a later call succeeds; a later
+ * call with fewer devices goes on with the first nDevices of those bound.
  * graftFramePlan is the piece list (pure host arithmetic; returns the number of pieces, writes at most `cap`
  * entries per array, any array may be NULL): piece k covers rows [firstRow[k], firstRow[k] + rows[k]), belongs to
  * GPU owner[k] and starts at row rowInOwner[k] of that GPU's own buffer of ownedRows[owner[k]] rows (ownedRows has
  * nDevices entries); graftFramePieces is the same without the last two.  graftRenderFrameMulti is graftRenderRows for
  * the whole frame over all bound GPUs, host buffers out; with one GPU bound it IS graftRenderRows.  The scene is packed
- * once and uploaded to every GPU; traces leave 4 CUs of every GPU to the transfer kernels.  graftMultiStats reports,
+ * once and uploaded to every GPU; traces leave 4 CUs of every GPU to the transfer kernels; the rows of every finished
+ * round leave the root for the host (page-locked memory: graftHostAlloc) while the later rounds are traced.  graftMultiStats reports,
  * for one GPU of the last multi-GPU frame, the time from its first kernel to its last (traceMs) and from its last
  * kernel to its last transfer (tailMs: the part of the exchange tracing did not hide; negative if none). */
 GRAFT_API int graftInitDevices(int nDevices);

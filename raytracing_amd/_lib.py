@@ -14,7 +14,8 @@ GRAFT_OK, GRAFT_ERR_ARG, GRAFT_ERR_UNSUPPORTED, GRAFT_ERR_HIP, GRAFT_ERR_STATE =
 GRAFT_SPHERE, GRAFT_PLANE = 0, 1
 GRAFT_ORTHOGRAPHIC, GRAFT_PERSPECTIVE = 0, 1
 GRAFT_OUT_F64_RGB, GRAFT_OUT_F32_RGBA, GRAFT_OUT_U8_RGBA = 0, 1, 2
-DIAGNOSTICS = {"screen_cap": 0, "group_size": 1, "tiles_per_ticket": 2, "table_builds": 4, "reserved_cus": 5, "copy_piece_kb": 6}
+DIAGNOSTICS = {"screen_cap": 0, "group_size": 1, "tiles_per_ticket": 2, "table_builds": 4, "reserved_cus": 5, "copy_piece_kb": 6,
+               "emulated_devices": 7}
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)

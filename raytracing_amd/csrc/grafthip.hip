@@ -817,6 +817,7 @@ struct Reusable {
 };
 
 constexpr int kMaxDevices = 16;
+constexpr int kHostCopyRounds = 16;   // rounds of a multi-device frame whose rows leave for the host on their own (= Device::pieceTraced)
 constexpr int kMultiReservedCUs = 4;  // CUs a multi-device frame's traces leave to the transfer kernels
 constexpr size_t kScratchBytes = (size_t)4 << 20;  // device block of graftRenderRowsNoAlloc: tables + ticket counters
 
@@ -824,10 +825,12 @@ constexpr size_t kScratchBytes = (size_t)4 << 20;  // device block of graftRende
 struct Device {
     bool ready = false;
     int id = -1, numCU = 0;
+    int physical = -1;  // the HIP device behind it (= id, except for the emulated devices of graftInitDevices)
     hipStream_t stream = nullptr;
     Reusable frame, index, counters;      // device side of graftRenderRows' host buffers
     hipStream_t copyStream = nullptr;     // graftRenderRows: finished pieces of a large frame leave on it while the next are traced
     hipEvent_t pieceTraced[16] = {nullptr};
+    hipEvent_t roundMoved[16] = {nullptr};  // graftRenderFrameMulti, root: the transfers of a round have arrived
     Reusable arena;                       // device block of the job graftRenderRows keeps between calls
     std::vector<unsigned char> cacheKey;  // the input that job was packed from
     GraftJob *cacheJob = nullptr;
@@ -861,6 +864,14 @@ struct Rccl {
 };
 Rccl gRccl;
 int gMultiDevices = 0;  // devices 0 .. gMultiDevices-1 bound by graftInitDevices
+// Emulated devices (GRAFT_DIAG_EMULATED_DEVICES, for tests on a machine with fewer GPUs than the code path needs): with
+// n > 0 graftInitDevices may bind up to n devices, device d standing for HIP device d mod (GPUs present), each with its
+// own streams, buffers and copy of the job; pieces then move to the root with device-to-device copies on the sender's
+// transfer stream instead of RCCL send/receive (two ranks of one communicator cannot share a GPU).  Everything else
+// of a multi-device frame -- the plan, the buffers and offsets, the ordering of kernels, transfers and copies to the
+// host -- is the code that runs on real devices.
+int gEmulatedDevices = 0;
+bool gMultiEmulated = false;  // the devices bound by graftInitDevices are emulated ones
 // what the last multi-device frame measured per device (graftMultiStats)
 float gMultiTraceMs[kMaxDevices], gMultiTailMs[kMaxDevices];
 int gMultiStatsDevices = 0;
@@ -966,22 +977,26 @@ void describe(GraftJob *job, const PackedJob &J, void *base, bool owns, Device *
 
 void releaseDevice(Device &D);
 
-int initDevice(int device, Device **out) {
+// `physical` >= 0: entry `device` of the library's table stands for that HIP device (emulated devices, below).
+int initDevice(int device, Device **out, int physical = -1) {
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n || device >= kMaxDevices) return fail(GRAFT_ERR_ARG, "device %d of %d", device, n);
+    if (physical < 0) physical = device;
+    if (device < 0 || physical >= n || device >= kMaxDevices) return fail(GRAFT_ERR_ARG, "device %d of %d", device, n);
     Device &D = gDevices[device];
     if (!D.ready) {
         readSettingsOnce();
         D.id = device;
+        D.physical = physical;
         auto create = [&]() -> int {
-            HIP_TRY(hipSetDevice(device));
+            HIP_TRY(hipSetDevice(physical));
             hipDeviceProp_t prop;
-            HIP_TRY(hipGetDeviceProperties(&prop, device));
+            HIP_TRY(hipGetDeviceProperties(&prop, physical));
             D.numCU = prop.multiProcessorCount;
             HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
             HIP_TRY(hipStreamCreateWithFlags(&D.copyStream, hipStreamNonBlocking));
             for (hipEvent_t &e : D.pieceTraced) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (hipEvent_t &e : D.roundMoved) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             static_assert(sizeof(scratch) == kScratchBytes, "scratch size");
             HIP_TRY(hipGetSymbolAddress((void **)&D.scratch, HIP_SYMBOL(scratch)));  // this device's copy of the array
             HIP_TRY(hipHostMalloc((void **)&D.scratchStage, kScratchBytes, hipHostMallocDefault));
@@ -1002,7 +1017,7 @@ int initDevice(int device, Device **out) {
 
 void releaseDevice(Device &D) {
     if (!D.ready) return;
-    (void)hipSetDevice(D.id);
+    (void)hipSetDevice(D.physical);
     if (D.stream) {
         (void)hipStreamSynchronize(D.stream);
         (void)hipStreamDestroy(D.stream);
@@ -1013,6 +1028,10 @@ void releaseDevice(Device &D) {
     }
     D.copyStream = nullptr;
     for (hipEvent_t &e : D.pieceTraced) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    for (hipEvent_t &e : D.roundMoved) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
     }
@@ -1166,6 +1185,10 @@ GRAFT_API int graftDiagnosticSet(int which, int value) {
             if (value < 0) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: copy pieces of %d KiB", value);
             gSettings.copyPieceKB = value;
             return GRAFT_OK;
+        case GRAFT_DIAG_EMULATED_DEVICES:
+            if (value < 0 || value > kMaxDevices) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: %d emulated devices", value);
+            gEmulatedDevices = value;
+            return GRAFT_OK;
         default:
             return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: unknown setting %d", which);
     }
@@ -1179,6 +1202,7 @@ GRAFT_API int graftDiagnosticGet(int which) {
         case GRAFT_DIAG_TILES_PER_TICKET: return gSettings.tilesPerTicket;
         case GRAFT_DIAG_RESERVED_CUS: return gSettings.reservedCUs;
         case GRAFT_DIAG_COPY_PIECE_KB: return gSettings.copyPieceKB;
+        case GRAFT_DIAG_EMULATED_DEVICES: return gEmulatedDevices;
         case GRAFT_DIAG_TABLE_BUILDS: return (int)(gTables.builds & 0x7fffffff);
         default: return -1;
     }
@@ -1504,26 +1528,30 @@ GRAFT_API int graftFramePieces(int nRows, int nDevices, int piecesPerDevice, int
 GRAFT_API int graftInitDevices(int nDevices) {
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
-    if (nDevices < 1 || nDevices > n || nDevices > kMaxDevices)
+    const bool emulate = nDevices > n && nDevices <= gEmulatedDevices && n >= 1;
+    if (nDevices < 1 || (nDevices > n && !emulate) || nDevices > kMaxDevices)
         return fail(GRAFT_ERR_ARG, "graftInitDevices: %d devices asked for, %d present (at most %d)", nDevices, n, kMaxDevices);
     if (gBound && gBound->id != 0) return fail(GRAFT_ERR_STATE, "graftInitDevices: already bound to device %d (device 0 is the root)", gBound->id);
-    if (gMultiDevices >= nDevices) return GRAFT_OK;
+    if (gMultiDevices >= nDevices) {  // the first nDevices of the devices bound already (ranks 0 .. n-1 of their communicator exchange among themselves)
+        gMultiDevices = nDevices;
+        return GRAFT_OK;
+    }
     // Until every step below has succeeded no multi-device frame can be started: a failure leaves the library with
     // device 0 only (gMultiDevices = 0: graftRenderFrameMulti refuses), never with half a set of communicators.
     const int before = gMultiDevices;
     gMultiDevices = 0;
     for (int d = 0; d < nDevices; ++d) {
         Device *D = nullptr;
-        const int rc = initDevice(d, &D);
+        const int rc = initDevice(d, &D, emulate ? d % n : d);
         if (rc != GRAFT_OK) return rc;
-        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipSetDevice(D->physical));
         if (!D->moveStream) HIP_TRY(hipStreamCreateWithFlags(&D->moveStream, hipStreamNonBlocking));
         if (!D->traced) HIP_TRY(hipEventCreateWithFlags(&D->traced, hipEventDisableTiming));
         if (!D->frameStart) HIP_TRY(hipEventCreate(&D->frameStart));
         if (!D->kernelsDone) HIP_TRY(hipEventCreate(&D->kernelsDone));
         if (!D->movesDone) HIP_TRY(hipEventCreate(&D->movesDone));
     }
-    if (nDevices > 1) {
+    if (nDevices > 1 && !emulate) {
         if (!gRccl.handle) {
             void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
             if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
@@ -1557,6 +1585,7 @@ GRAFT_API int graftInitDevices(int nDevices) {
     HIP_TRY(hipSetDevice(0));
     gBound = &gDevices[0];
     gMultiDevices = nDevices;
+    gMultiEmulated = emulate;
     return GRAFT_OK;
 }
 
@@ -1582,7 +1611,7 @@ static int cachedJobs(int G, const GraftScene *scene, const GraftView *view, Gra
             if (rc != GRAFT_OK) return fail(rc, "graftRenderFrameMulti: %s", err.c_str());
             packed = true;
         }
-        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipSetDevice(D->physical));
         D->cacheKey.clear();  // whatever happens below, the old job's block is about to be overwritten
         hipError_t e = D->arena.reserve(J.image.size());
         if (e != hipSuccess) return fail(GRAFT_ERR_HIP, "hipMalloc(%zu) on device %d: %s", J.image.size(), d, hipGetErrorString(e));
@@ -1618,8 +1647,9 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
         if (!view) return fail(GRAFT_ERR_ARG, "graftRenderFrameMulti: null view");
         return graftRenderRows(scene, view, 0, view->nRows, format, frameHost, hitIndexHost, countersHost);
     }
+    const bool emulated = gMultiEmulated;
     for (int d = 0; d < G; ++d)
-        if (!gDevices[d].comm || !gDevices[d].moveStream)
+        if ((!emulated && !gDevices[d].comm) || !gDevices[d].moveStream)
             return fail(GRAFT_ERR_STATE, "graftRenderFrameMulti: device %d has no communicator (graftInitDevices failed?)", d);
     int rc = GRAFT_OK;
     bool groupOpen = false;
@@ -1629,6 +1659,7 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
     GraftCounters sum = {0, 0, 0, 0};
     Device &root = gDevices[0];
     int nPieces = 0, rounds = 0, nCols = 0, nRows = 0;
+    size_t hostRows = 0;
     // A trace that shares its GPU with RCCL's send/receive kernels leaves them a few CUs: without that the transfer of
     // round c could only start when a persistent workgroup of round c + 1's trace retires, i.e. near its end.
     const int reservedBefore = gSettings.reservedCUs;
@@ -1642,7 +1673,7 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
     // buffers: the root holds the whole frame, every other device its own pieces
     for (int d = 0; d < G; ++d) {
         Device &D = gDevices[d];
-        HIP_GO(hipSetDevice(d));
+        HIP_GO(hipSetDevice(D.physical));
         const size_t rowsHere = d == 0 ? (size_t)nRows : (size_t)ownedRows[d];
         HIP_GO((d == 0 ? D.frame : D.pieces).reserve(rowsHere * nCols * pixelBytes + 16));
         if (hitIndexHost) HIP_GO((d == 0 ? D.index : D.pieceIndex).reserve(rowsHere * nCols * 4 + 16));
@@ -1661,7 +1692,7 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
     for (int c = 0; c < rounds; ++c) {
         for (int k = c * G; k < nPieces && k < (c + 1) * G; ++k) {
             Device &D = gDevices[owner[k]];
-            HIP_GO(hipSetDevice(D.id));
+            HIP_GO(hipSetDevice(D.physical));
             unsigned char *frame = owner[k] == 0 ? (unsigned char *)D.frame.ptr + (size_t)first[k] * nCols * pixelBytes
                                                  : (unsigned char *)D.pieces.ptr + (size_t)at[k] * nCols * pixelBytes;
             int32_t *index = !hitIndexHost ? nullptr
@@ -1673,29 +1704,63 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
             if (owner[k] != 0) {
                 HIP_GO(hipEventRecord(D.traced, D.stream));
                 HIP_GO(hipStreamWaitEvent(D.moveStream, D.traced, 0));
+            } else if (c < kHostCopyRounds) {
+                HIP_GO(hipEventRecord(D.pieceTraced[c], D.stream));  // the root's own piece of this round is in its frame
             }
         }
-        NCCL_TRY(gRccl.groupStart());
-        groupOpen = true;
+        if (!emulated) {
+            NCCL_TRY(gRccl.groupStart());
+            groupOpen = true;
+        }
         for (int k = c * G; k < nPieces && k < (c + 1) * G; ++k) {
             if (owner[k] == 0) continue;
             Device &D = gDevices[owner[k]];
-            const size_t bytes = (size_t)count[k] * nCols * pixelBytes;
-            NCCL_TRY(gRccl.send((unsigned char *)D.pieces.ptr + (size_t)at[k] * nCols * pixelBytes, bytes, ncclChar, 0, D.comm, D.moveStream));
-            NCCL_TRY(gRccl.recv((unsigned char *)root.frame.ptr + (size_t)first[k] * nCols * pixelBytes, bytes, ncclChar, owner[k],
-                                root.comm, root.moveStream));
+            const size_t bytes = (size_t)count[k] * nCols * pixelBytes, ib = (size_t)count[k] * nCols * 4;
+            unsigned char *src = (unsigned char *)D.pieces.ptr + (size_t)at[k] * nCols * pixelBytes;
+            unsigned char *dst = (unsigned char *)root.frame.ptr + (size_t)first[k] * nCols * pixelBytes;
+            int32_t *srcIndex = hitIndexHost ? (int32_t *)D.pieceIndex.ptr + (size_t)at[k] * nCols : nullptr;
+            int32_t *dstIndex = hitIndexHost ? (int32_t *)root.index.ptr + (size_t)first[k] * nCols : nullptr;
+            if (emulated) {  // the sender's transfer stream copies the piece; the root's transfer stream waits for it
+                HIP_GO(hipSetDevice(D.physical));
+                HIP_GO(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, D.moveStream));
+                if (hitIndexHost) HIP_GO(hipMemcpyAsync(dstIndex, srcIndex, ib, hipMemcpyDeviceToDevice, D.moveStream));
+                HIP_GO(hipEventRecord(D.traced, D.moveStream));  // (its wait on the kernel has been queued: the event is free again)
+                HIP_GO(hipSetDevice(root.physical));
+                HIP_GO(hipStreamWaitEvent(root.moveStream, D.traced, 0));
+                continue;
+            }
+            NCCL_TRY(gRccl.send(src, bytes, ncclChar, 0, D.comm, D.moveStream));
+            NCCL_TRY(gRccl.recv(dst, bytes, ncclChar, owner[k], root.comm, root.moveStream));
             if (hitIndexHost) {
-                const size_t ib = (size_t)count[k] * nCols * 4;
-                NCCL_TRY(gRccl.send((int32_t *)D.pieceIndex.ptr + (size_t)at[k] * nCols, ib, ncclChar, 0, D.comm, D.moveStream));
-                NCCL_TRY(gRccl.recv((int32_t *)root.index.ptr + (size_t)first[k] * nCols, ib, ncclChar, owner[k], root.comm, root.moveStream));
+                NCCL_TRY(gRccl.send(srcIndex, ib, ncclChar, 0, D.comm, D.moveStream));
+                NCCL_TRY(gRccl.recv(dstIndex, ib, ncclChar, owner[k], root.comm, root.moveStream));
             }
         }
-        groupOpen = false;
-        NCCL_TRY(gRccl.groupEnd());
+        if (!emulated) {
+            groupOpen = false;
+            NCCL_TRY(gRccl.groupEnd());
+        }
+        // The pieces of round c are neighbours in the frame (pieces are dealt in row order): once the root's own kernel and
+        // the round's transfers are done, that block of rows leaves for the host on the root's copy stream, beside the
+        // tracing and the transfers of the later rounds.
+        if (c < kHostCopyRounds) {
+            const int kFirst = c * G, kLast = (nPieces < (c + 1) * G ? nPieces : (c + 1) * G) - 1;
+            const size_t row0 = (size_t)first[kFirst], rows = (size_t)(first[kLast] + count[kLast]) - row0;
+            HIP_GO(hipSetDevice(root.physical));
+            HIP_GO(hipEventRecord(root.roundMoved[c], root.moveStream));
+            HIP_GO(hipStreamWaitEvent(root.copyStream, root.roundMoved[c], 0));
+            if (owner[kFirst] == 0) HIP_GO(hipStreamWaitEvent(root.copyStream, root.pieceTraced[c], 0));
+            HIP_GO(hipMemcpyAsync((unsigned char *)frameHost + row0 * nCols * pixelBytes, (unsigned char *)root.frame.ptr + row0 * nCols * pixelBytes,
+                                  rows * nCols * pixelBytes, hipMemcpyDeviceToHost, root.copyStream));
+            if (hitIndexHost)
+                HIP_GO(hipMemcpyAsync(hitIndexHost + row0 * nCols, (int32_t *)root.index.ptr + row0 * nCols, rows * nCols * 4,
+                                      hipMemcpyDeviceToHost, root.copyStream));
+            hostRows = row0 + rows;  // rows [0, hostRows) are on their way to the host
+        }
     }
     // the assembled frame leaves the root once its own kernels and every transfer are done
     for (int d = 0; d < G; ++d) {
-        HIP_GO(hipSetDevice(d));
+        HIP_GO(hipSetDevice(gDevices[d].physical));
         HIP_GO(hipEventRecord(gDevices[d].movesDone, gDevices[d].moveStream));
         HIP_GO(hipStreamSynchronize(gDevices[d].stream));
         HIP_GO(hipStreamSynchronize(gDevices[d].moveStream));
@@ -1713,16 +1778,23 @@ GRAFT_API int graftRenderFrameMulti(const GraftScene *scene, const GraftView *vi
     }
     gMultiStatsDevices = G;
     HIP_GO(hipSetDevice(0));
-    HIP_GO(hipMemcpy(frameHost, root.frame.ptr, (size_t)nRows * nCols * pixelBytes, hipMemcpyDeviceToHost));
-    if (hitIndexHost) HIP_GO(hipMemcpy(hitIndexHost, root.index.ptr, (size_t)nRows * nCols * 4, hipMemcpyDeviceToHost));
+    HIP_GO(hipStreamSynchronize(root.copyStream));
+    if (hostRows < (size_t)nRows) {  // (more rounds than copy events: the rest of the frame in one piece)
+        HIP_GO(hipMemcpy((unsigned char *)frameHost + hostRows * nCols * pixelBytes, (unsigned char *)root.frame.ptr + hostRows * nCols * pixelBytes,
+                         ((size_t)nRows - hostRows) * nCols * pixelBytes, hipMemcpyDeviceToHost));
+        if (hitIndexHost)
+            HIP_GO(hipMemcpy(hitIndexHost + hostRows * nCols, (int32_t *)root.index.ptr + hostRows * nCols, ((size_t)nRows - hostRows) * nCols * 4,
+                             hipMemcpyDeviceToHost));
+    }
     if (countersHost) *countersHost = sum;
 done:
     if (groupOpen) (void)gRccl.groupEnd();  // never leave a group open behind an error
     if (rc != GRAFT_OK)
         for (int d = 0; d < G; ++d) {  // let what was queued drain before the caller sees the error
-            (void)hipSetDevice(d);
+            (void)hipSetDevice(gDevices[d].physical);
             if (gDevices[d].stream) (void)hipStreamSynchronize(gDevices[d].stream);
             if (gDevices[d].moveStream) (void)hipStreamSynchronize(gDevices[d].moveStream);
+            if (gDevices[d].copyStream) (void)hipStreamSynchronize(gDevices[d].copyStream);
         }
     gSettings.reservedCUs = reservedBefore;
     (void)hipSetDevice(0);

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -36,9 +37,14 @@ inline void parallelRanges(int n, int grain, Body body) {
     }
     std::vector<std::thread> pool;
     pool.reserve((size_t)t - 1);
-    for (int i = 1; i < t; ++i)
-        pool.emplace_back([&body, n, t, i] { body((int)((long long)n * i / t), (int)((long long)n * (i + 1) / t)); });
-    body(0, (int)((long long)n / t));
+    auto range = [&body, n, t](int i) { body((int)((long long)n * i / t), (int)((long long)n * (i + 1) / t)); };
+    int started = 1;  // (range 0 is the calling thread's)
+    try {
+        for (; started < t; ++started) pool.emplace_back(range, started);
+    } catch (const std::system_error &) {  // no more threads to be had: the calling thread takes the ranges that are left
+    }
+    range(0);
+    for (int i = started; i < t; ++i) range(i);
     for (std::thread &th : pool) th.join();
 }
 

@@ -332,3 +332,38 @@ def test_multi_device_entry_with_the_devices_present(gpu):
     assert np.array_equal(idx, want["index"])
     assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64))
     assert rt.last_counters == want["counters"][:2]
+
+
+def test_multi_device_frame_on_emulated_devices(gpu):
+    """The multi-device frame with more devices than the box has GPUs: devices 0..2 (and then 0..4) all stand for the GPUs
+    present, each with its own streams, buffers and copy of the job, and the pieces reach the root by device-to-device
+    copies instead of RCCL.  Everything else -- the plan, offsets into the owners' buffers, the ordering of kernels,
+    transfers and the copies of finished rounds to the host -- is the code real devices run.  Frames, index planes
+    and counters against the oracle, in every format's own terms; uneven piece counts; more rounds than copy events."""
+    import raytracing_amd
+    from raytracing_amd import multi_stats
+    old = raytracing_amd.set_diagnostic("emulated_devices", 5)
+    try:
+        rt = build("cfg5_128_depth4")
+        want = ob.render(rt, threads=THREADS, want_index=True, want_counters=True)
+        for devices, pieces in ((3, 3), (3, 1), (5, 2), (5, 40)):   # 128 rows = 16 rows of tiles: 5 x 40 is cut down to 16 pieces
+            raytracing_amd.init_devices(devices)
+            rgb, idx = rt.render_frame_multi(GRAFT_OUT_F64_RGB, pieces, want_index=True, want_counters=True)
+            assert np.array_equal(idx, want["index"]), (devices, pieces)
+            assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64)), (devices, pieces)
+            assert rt.last_counters == want["counters"][:2]
+            trace_ms, tail_ms = multi_stats(devices - 1)   # the last device took part and was timed
+            assert trace_ms >= 0
+            rgba = rt.render_frame_multi(GRAFT_OUT_U8_RGBA, pieces)
+            q = (np.clip(np.nan_to_num(want["rgb"]), 0, 1) * 255 + 0.5).astype(np.uint8)
+            assert np.array_equal(rgba[..., :3], q) and np.all(rgba[..., 3] == 255)
+        # a frame of many rounds: 18 rounds of 3 devices, two more than the root has copy events
+        rt = build("single_sphere")
+        want = ob.render(rt, threads=THREADS, want_index=True)
+        raytracing_amd.init_devices(3)
+        rgb, idx = rt.render_frame_multi(GRAFT_OUT_F64_RGB, 18, want_index=True)
+        assert np.array_equal(idx, want["index"]) and np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64))
+    finally:
+        raytracing_amd.init_devices(raytracing_amd.device_count())   # back to the GPUs present
+        raytracing_amd.set_diagnostic("emulated_devices", old)
+
