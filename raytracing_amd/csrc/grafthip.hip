@@ -218,7 +218,9 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     // per ticket; counters in different cache lines add up.
     // One counter (expensive tiles): a wave's first ticket is its own number (the host starts the counter at the
     // number of waves); the next ticket is drawn when a ticket's first tile starts and only read after its last
-    // tile, so the atomic's round trip overlaps the work.
+    // tile, so the atomic's round trip overlaps the work.  With candidate lists many tiles are cheap after all (an
+    // empty tile list: background only) and a frame of them runs at the counter's pace: tickets hold four tiles
+    // until the end of the launch is near, and one tile from there on.
     // kCursors counters (cheap tiles): counter c hands out tickets c, c + kCursors, ...; a wave starts at counter
     // (wave number mod kCursors) and moves on to the next counter when one is used up, until all are.  The next
     // ticket is drawn ahead only when there are plenty per wave (P.prefetchTickets): a wave holding a spare ticket
@@ -246,10 +248,13 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 listEnd = tile;
                 if (P.prefetchTickets && lane == 0) nextTicket = atomicAdd(P.tileCursor + cursor * kCursorStride, 1);
             } else {
+                // (the first P.coarseTickets tickets hold tilesPerTicket tiles each, the tickets after them -- the end of
+                // the launch, where waves must not be left holding several expensive tiles -- one tile)
                 const int ticket = __builtin_amdgcn_readfirstlane(nextTicket);
-                tile = ticket * P.tilesPerTicket;
+                const int fine = ticket - P.coarseTickets;
+                tile = fine < 0 ? ticket * P.tilesPerTicket : P.coarseTickets * P.tilesPerTicket + fine;
                 if (tile >= P.numTiles) break;  // every wave reaches this: the counter only grows
-                tileEnd = min(tile + P.tilesPerTicket, P.numTiles);
+                tileEnd = min(tile + (fine < 0 ? P.tilesPerTicket : 1), P.numTiles);
                 if (lane == 0) nextTicket = atomicAdd(P.tileCursor, 1);
             }
         }
@@ -1111,8 +1116,21 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     // (with candidate lists a ticket's tiles share one tile list per row of tiles: longer tickets)
     long long perTicket = manyCursors ? (job->screen >= 6 && !job->mirrors ? 4 : 2) : 1;
     if (perTicket * waves * 8 > tiles) perTicket = tiles / (waves * 8) < 1 ? 1 : tiles / (waves * 8);
-    if (gSettings.tilesPerTicket > 0) perTicket = gSettings.tilesPerTicket;  // diagnostics: forced ticket size
+#ifndef GRAFT_COARSE_TILES
+#define GRAFT_COARSE_TILES 4
+#endif
+    // one counter: with candidate lists, tickets of four tiles except for the last 16 tiles per wave
+    long long coarse = 0;
+    if (!manyCursors && job->screen >= 6 && tiles > waves * 16) {
+        perTicket = GRAFT_COARSE_TILES;
+        coarse = (tiles - waves * 16) / perTicket;
+    }
+    if (gSettings.tilesPerTicket > 0) {  // diagnostics: forced ticket size (one counter: for every ticket but the last)
+        perTicket = gSettings.tilesPerTicket;
+        coarse = manyCursors ? 0 : tiles / perTicket;
+    }
     P.tilesPerTicket = (int)perTicket;
+    P.coarseTickets = (int)coarse;
     P.prefetchTickets = (tiles + perTicket - 1) / perTicket >= 8 * waves ? 1 : 0;
     if (manyCursors) HIP_TRY(hipMemsetAsync(P.tileCursor, 0, sizeof(int) * kCursors * kCursorStride, s));
     else HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)P.tileCursor, grid * wavesPerBlock, 1, s));

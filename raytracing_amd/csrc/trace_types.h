@@ -105,6 +105,7 @@ struct TraceParams {
     int tilesX, numTiles;
     int tilesPerTicket;        // consecutive tiles a wave takes per draw from a counter
     int prefetchTickets;       // draw the next ticket one ticket ahead (plenty of tickets per wave)
+    int coarseTickets;         // one counter: tickets below this number hold tilesPerTicket tiles, the later ones one tile
     int geomDoubles;           // doubles of packed geometry (spheres 4 each, then planes 6 each)
     int avoidTotal;            // shapes on the lights' avoid lists, all lights together (ray-shape evaluations they spare)
     int skipLightsBehind;      // lights behind the shaded surface may go unasked: every colour, weight and colour product of
