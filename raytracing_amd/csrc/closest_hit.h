@@ -929,6 +929,53 @@ __device__ __forceinline__ bool coneMeetsTile(const float4v e, float sinA, const
     return c + 1e-9 >= __builtin_fma(-(double)sinA, T.sinT, (double)e.w * T.cosT);
 }
 
+// The tile list of an ORTHOGRAPHIC view: every primary ray has the direction d = unit(-viewDir) (mainTracing.c:410-413)
+// and starts at screenCenter + x lrUnit + y udUnit; in the plane across d through the screen centre its line crosses at
+// x P(lrUnit) + y P(udUnit) (P takes the component along d out; the camera block holds the projected vectors), within
+// (half width + half height) of the tile's centre w since the projected vectors are no longer than 1.  An entry {q, R}
+// of the table (packOrthoTable: R holds the radius, the margin and the rounding to float) can be met iff
+// |q - w| <= R + half width + half height (+ a slack for the rounding of the rays' own screen points).
+template <bool GLOBAL>
+__device__ __forceinline__ int buildTileListOrtho(const TraceParams &P, ConstDoubles C, double xLo, double xHi, double yLo,
+                                                  double yHi, unsigned short *list) {
+    const int lane = lane64();
+    const double xc = 0.5 * (xLo + xHi), yc = 0.5 * (yLo + yHi);
+    double w[3];
+    for (int a = 0; a < 3; ++a) w[a] = xc * C[CAM_LRUNIT + a] + yc * C[CAM_UDUNIT + a];
+    const double reach = (0.5 * (xHi - xLo) + 0.5 * (yHi - yLo)) * (1.0 + 1e-9) + 1e-9 * P.familyScale;
+    if (!(reach >= 0 && reach < 1e300) || !(w[0] - w[0] == 0 && w[1] - w[1] == 0 && w[2] - w[2] == 0)) return -1;  // (NaN, infinite)
+    auto meets = [&](const float4v e) {
+        const double dx = (double)e.x - w[0], dy = (double)e.y - w[1], dz = (double)e.z - w[2];
+        const double rr = (double)e.w + reach;  // (-inf for padding entries: never)
+        return rr >= 0 && __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)) <= rr * rr * (1.0 + 1e-12);
+    };
+    const char *image = GLOBAL ? (const char *)P.geomF : (const char *)ldsGeom;
+    const float4v *groups = (const float4v *)((const char *)ldsGeom + P.listGroupsOff);
+    const float4v *members = (const float4v *)(image + P.listMembersOff);
+    const unsigned short *shapeOf = (const unsigned short *)(image + P.listShapeOff);
+    const int gs = P.groupSize;
+    int count = 0;
+    for (int g0 = 0; g0 < P.listGroups; g0 += 64) {
+        const int g = g0 + lane;
+        unsigned long long open = __ballot(g < P.listGroups && meets(groups[g < P.listGroups ? g : 0]));
+        while (open) {
+            const int gOpen = g0 + (int)__builtin_ctzll(open);
+            open &= open - 1;
+            bool take = false;
+            unsigned short id = 0xffff;
+            if (lane < gs) {
+                id = shapeOf[gOpen * gs + lane];
+                take = id != 0xffff && meets(members[gOpen * gs + lane]);
+            }
+            const unsigned long long taken = __ballot(take);
+            const int at = count + (int)__popcll(taken & ((1ull << lane) - 1));
+            if (take && at < kTileListCap) list[at] = id;
+            count += (int)__popcll(taken);
+        }
+    }
+    return count <= kTileListCap ? count : -1;
+}
+
 // The wave's tile list: sphere numbers (16 bits) at `list` in LDS; returns the count, or -1 when the list would
 // exceed kTileListCap entries or the tile has no usable bounding cone (the caller then lists every sphere).  Called by
 // all 64 lanes.  (xLo, xHi) x (yLo, yHi): world offsets on the screen plane that bound every sample of the tile.
@@ -936,6 +983,7 @@ template <bool GLOBAL>
 __device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles C, double xLo, double xHi, double yLo,
                                              double yHi, unsigned short *list) {
     const int lane = lane64();
+    if (P.projectionType == GRAFT_ORTHOGRAPHIC) return buildTileListOrtho<GLOBAL>(P, C, xLo, xHi, yLo, yHi, list);
     auto towards = [&](double x, double y, double v[3]) {
         for (int a = 0; a < 3; ++a) v[a] = C[CAM_TOSCREEN + a] + x * C[CAM_LRUNIT + a] + y * C[CAM_UDUNIT + a];
     };

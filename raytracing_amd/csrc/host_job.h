@@ -57,6 +57,11 @@ struct TableCache {
         TwoLevelTable table;
     };
     std::list<Cone> cones;  // a list: references handed out stay valid while others are added
+    struct Ortho {          // camera table of an orthographic view (packOrthoTable)
+        double centre[3], dir[3], scale;
+        OrthoTable table;
+    };
+    std::list<Ortho> orthos;
     struct Occluders {      // occluder lists of one light (packLightLists)
         double light[3], scale;
         std::vector<unsigned char> avoid;  // the light's avoid row (empty: nothing avoided)
@@ -72,10 +77,12 @@ struct TableCache {
         haveBalls = ballsOk = false;
         haveGrid = gridOk = false;
         cones.clear();
+        orthos.clear();
         occluders.clear();
     }
     void makeRoom(size_t wanted) {  // call before a round of cone() / occluderLists() calls, never between them
         if (cones.size() + wanted > 32) cones.clear();
+        if (orthos.size() > 8) orthos.clear();
         if (occluders.size() + wanted > 32) occluders.clear();
     }
     const Occluders &occluderLists(const double light[3], double scale, const unsigned char *avoidRow, size_t n) {
@@ -92,6 +99,18 @@ struct TableCache {
         o.ok = packLightLists(sph, light, scale, avoidRow, o.lists);
         builds++;
         return o;
+    }
+    const OrthoTable &ortho(const double centre[3], const double dir[3], double scale) {
+        for (Ortho &o : orthos)
+            if (memcmp(o.centre, centre, sizeof o.centre) == 0 && memcmp(o.dir, dir, sizeof o.dir) == 0 && o.scale == scale) return o.table;
+        orthos.emplace_back();
+        Ortho &o = orthos.back();
+        memcpy(o.centre, centre, sizeof o.centre);
+        memcpy(o.dir, dir, sizeof o.dir);
+        o.scale = scale;
+        packOrthoTable(sph, centre, dir, scale, groupSize, o.table);
+        builds++;
+        return o.table;
     }
     const TwoLevelTable &cone(const double apex[3], double scale) {
         for (Cone &c : cones)
@@ -180,8 +199,21 @@ inline bool packLists(TableCache &cache, const std::vector<double> &sph, const G
         if (!cache.gridOk) return false;
     }
     const GridTable &grid = cache.grid;
-    const TwoLevelTable &cam = cache.cone(view->camPos, scale);
-    const size_t gs = (size_t)cam.kGroup, G = cam.memberShape.size() / gs;
+    // the camera table: cones seen from the camera, or -- orthographic view -- balls in the plane across the rays
+    const bool ortho = view->projectionType == GRAFT_ORTHOGRAPHIC;
+    const TwoLevelTable *camTable = nullptr;
+    const OrthoTable *orthoTable = nullptr;
+    if (ortho) {
+        const double vv = view->viewDir[0] * view->viewDir[0] + view->viewDir[1] * view->viewDir[1] + view->viewDir[2] * view->viewDir[2];
+        if (!(vv > 1e-200 && vv < 1e200)) return false;
+        const double len = sqrt(vv);
+        const double dir[3] = {-view->viewDir[0] / len, -view->viewDir[1] / len, -view->viewDir[2] / len};  // mainTracing.c:410-413
+        orthoTable = &cache.ortho(view->screenCenter, dir, scale);
+    } else {
+        camTable = &cache.cone(view->camPos, scale);
+    }
+    const std::vector<int> &camShape = ortho ? orthoTable->memberShape : camTable->memberShape;
+    const size_t gs = (size_t)(ortho ? orthoTable->kGroup : camTable->kGroup), G = camShape.size() / gs;
     std::vector<const LightLists *> lists;
     for (size_t i = 0; i < nL; ++i) {
         const unsigned char *row = lights[i].avoidNum > 0 ? mask.data() + i * (size_t)nS : nullptr;
@@ -239,7 +271,7 @@ inline bool packLists(TableCache &cache, const std::vector<double> &sph, const G
     // sine up (either way the cone only widens); an entry that always passes gets cos = -2, one that never does +inf
     auto coneEntries = [&](size_t first, size_t count, size_t oEntries, size_t oSin) {
         std::vector<float> plain;
-        unpackEntries(cam.entries, first, count, plain);
+        unpackEntries(camTable->entries, first, count, plain);
         for (size_t e = 0; e < count; ++e) {
             const double k2 = -(double)plain[4 * e + 3];
             float c = INFINITY, sn = 0.0f;
@@ -254,10 +286,15 @@ inline bool packLists(TableCache &cache, const std::vector<double> &sph, const G
             memcpy(&img[oSin + 4 * e], &sn, 4);
         }
     };
-    coneEntries(0, G, oGroups, oSines);
-    coneEntries((size_t)cam.memberBase, G * gs, oMembers, oMemberSines);
+    if (ortho) {  // {q, R} entries as they are; the sines' slots stay zero
+        memcpy(&img[oGroups], orthoTable->groups.data(), 16 * G);
+        memcpy(&img[oMembers], orthoTable->members.data(), 16 * G * gs);
+    } else {
+        coneEntries(0, G, oGroups, oSines);
+        coneEntries((size_t)camTable->memberBase, G * gs, oMembers, oMemberSines);
+    }
     for (size_t m = 0; m < G * gs; ++m) {
-        const unsigned short id = cam.memberShape[m] < 0 ? (unsigned short)0xffff : (unsigned short)cam.memberShape[m];
+        const unsigned short id = camShape[m] < 0 ? (unsigned short)0xffff : (unsigned short)camShape[m];
         memcpy(&img[oShape + 2 * m], &id, 2);
     }
     for (size_t k = 0; k < n; ++k)
@@ -374,6 +411,22 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
         cam.lrUnit[c] = cam.lrVec[c] / sqrt(cam.lrDen);
         cam.udUnit[c] = cam.udVec[c] / sqrt(cam.udDen);
     }
+    if (view->projectionType == GRAFT_ORTHOGRAPHIC) {
+        // orthographic tile lists work in the plane across the rays: the unit vectors along lrVec and udVec with their
+        // components along the rays' direction taken out (zero for the reference's own views, whose three vectors are
+        // perpendicular; any other view is covered as well)
+        const double vv = cam.viewDir[0] * cam.viewDir[0] + cam.viewDir[1] * cam.viewDir[1] + cam.viewDir[2] * cam.viewDir[2];
+        if (vv > 1e-200 && vv < 1e200) {
+            const double len = sqrt(vv);
+            const double dir[3] = {-cam.viewDir[0] / len, -cam.viewDir[1] / len, -cam.viewDir[2] / len};
+            const double lrAlong = cam.lrUnit[0] * dir[0] + cam.lrUnit[1] * dir[1] + cam.lrUnit[2] * dir[2];
+            const double udAlong = cam.udUnit[0] * dir[0] + cam.udUnit[1] * dir[1] + cam.udUnit[2] * dir[2];
+            for (int c = 0; c < 3; ++c) {
+                cam.lrUnit[c] -= lrAlong * dir[c];
+                cam.udUnit[c] -= udAlong * dir[c];
+            }
+        }
+    }
     P.projectionType = view->projectionType; P.aliasing = view->aliasing ? 1 : 0;
     P.numPasses = view->numPasses; P.maxDepth = scene->maxDepth;
     P.numShapes = nS; P.numLights = nL; P.numRuns = (int)runs.size(); P.numSpheres = (int)(sph.size() / 4);
@@ -455,7 +508,7 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     bool spheresInRange = sph.size() / 4 >= 64;
     for (size_t k = 0; k < sph.size() / 4 && spheresInRange; ++k)  // (what packBallTable asks of a scene; rejects NaN)
         spheresInRange = fabs(sph[4 * k]) + fabs(sph[4 * k + 1]) + fabs(sph[4 * k + 2]) + sqrt(sph[4 * k + 3]) < kGroupScale;
-    if (wantGroups && screenCap >= 6 && nL <= 7 && lightBase == 1 && scale < kGroupScale && spheresInRange) {
+    if (wantGroups && screenCap >= 6 && nL <= 7 && scale < kGroupScale && spheresInRange) {
         if (cache.groupSize != groupSize || cache.sph != sph) cache.reset(sph, groupSize);
         cache.makeRoom(apexes.size());
         std::vector<float> image;

@@ -566,6 +566,61 @@ inline bool packLightLists(const std::vector<double> &sph, const double light[3]
     return true;
 }
 
+// The camera table of an ORTHOGRAPHIC view (closestHitLists): every primary ray has the same direction d, so what a ray
+// can meet depends on where its line crosses the plane through the screen centre perpendicular to d.  With P = I - d d^T
+// sphere j is the point q_j = P (c_j - screenCenter) of that plane and a line crossing it at w meets the sphere iff
+// |q_j - w| <= r_j.  An entry is {q, R} (single precision, R rounded up); group entries are bounding balls of their
+// members' (k-d leaves of the q).  R carries r_j, the margin m = 1.01 sqrt(eBound) (a sphere left out is missed by more
+// than m, so its double-precision discriminant in the reference, r^2 - distance^2 up to rounding below eBound, is
+// negative) and the rounding of q to float.  Entries as plain quadruples: groups[4 g], members[4 (g kGroup + i)],
+// memberShape -1 for padding (R = -inf: never passes).
+struct OrthoTable {
+    std::vector<float> groups, members;
+    std::vector<int> memberShape;
+    int kGroup = 0;
+};
+
+inline void packOrthoTable(const std::vector<double> &sph, const double centre[3], const double dir[3], double scale,
+                           int kGroup, OrthoTable &T) {
+    const int n = (int)(sph.size() / 4);
+    const double eBound = 1e-13 * (4 * scale) * (4 * scale);
+    const double margin = 1.01 * sqrt(eBound) + 1e-9 * scale;
+    const double roundOff = 4 * 5.9604644775390625e-08 * scale;  // (three coordinates rounded to float, and R itself)
+    std::vector<double> q(3 * (size_t)n), R(n);
+    for (int k = 0; k < n; ++k) {
+        const double *c = &sph[4 * (size_t)k];
+        const double v[3] = {c[0] - centre[0], c[1] - centre[1], c[2] - centre[2]};
+        const double along = v[0] * dir[0] + v[1] * dir[1] + v[2] * dir[2];
+        for (int a = 0; a < 3; ++a) q[3 * (size_t)k + a] = v[a] - along * dir[a];
+        R[k] = sqrt(c[3]) + margin + roundOff;
+    }
+    const std::vector<int> order = kdLeafOrder(q, n, kGroup);
+    const int nGroups = (n + kGroup - 1) / kGroup;
+    T.kGroup = kGroup;
+    T.groups.assign(4 * (size_t)nGroups, 0.0f);
+    T.members.assign(4 * (size_t)nGroups * kGroup, 0.0f);
+    T.memberShape.assign((size_t)nGroups * kGroup, -1);
+    for (size_t i = 0; i < (size_t)nGroups * kGroup; ++i) T.members[4 * i + 3] = -INFINITY;
+    auto up = [](double x) { float f = (float)x; return (double)f < x ? nextafterf(f, INFINITY) : f; };
+    for (int gI = 0; gI < nGroups; ++gI) {
+        const int first = gI * kGroup, last = std::min(n, first + kGroup);
+        double g[3] = {0, 0, 0};
+        for (int m = first; m < last; ++m)
+            for (int a = 0; a < 3; ++a) g[a] += q[3 * (size_t)order[m] + a] / (last - first);
+        double radius = 0;
+        for (int m = first; m < last; ++m) {
+            const int k = order[m];
+            const double *p = &q[3 * (size_t)k];
+            radius = fmax(radius, sqrt((p[0] - g[0]) * (p[0] - g[0]) + (p[1] - g[1]) * (p[1] - g[1]) + (p[2] - g[2]) * (p[2] - g[2])) + R[k]);
+            float *e = &T.members[4 * ((size_t)gI * kGroup + (m - first))];
+            e[0] = (float)p[0]; e[1] = (float)p[1]; e[2] = (float)p[2]; e[3] = up(R[k]);
+            T.memberShape[(size_t)gI * kGroup + (m - first)] = k;
+        }
+        float *e = &T.groups[4 * (size_t)gI];
+        e[0] = (float)g[0]; e[1] = (float)g[1]; e[2] = (float)g[2]; e[3] = up(radius * (1 + 1e-12) + roundOff);
+    }
+}
+
 // Interleave the tables of several ray families block by block (a block = 4 packed entries = 64 bytes): block b of
 // family f lands at float4 index 4 * (b * families + f), and the shape index of member entry i at i * families + f.
 // A lane then reads a block with one address and four fixed offsets, and lanes of one wave that trace rays of

@@ -14,7 +14,7 @@ import pytest
 
 import oracle_binding as ob
 from raytracing_amd import get_diagnostic, scenes, set_diagnostic
-from raytracing_amd.tracer import ANTIALIASING_OFF, GRAFT_OUT_F64_RGB, Light, RayTracer, lightInit
+from raytracing_amd.tracer import ANTIALIASING_OFF, GRAFT_OUT_F64_RGB, ORTHOGRAPHIC, Light, RayTracer, lightInit
 
 pytestmark = pytest.mark.gpu
 
@@ -41,6 +41,8 @@ def new_point(start, direction, dist):
 
 def primary_ray(rt, i, j):
     fin = new_point(new_point(rt.screenCenter, rt.lrVec, i), rt.udVec, j)
+    if rt.projectionType == ORTHOGRAPHIC:   # mainTracing.c:410-413
+        return fin, unit([-a for a in rt.viewDir])
     return fin, unit([a - b for a, b in zip(fin, rt.camPos)])
 
 
@@ -91,13 +93,15 @@ def tangent_radii(s, d, centre, r):
     return out
 
 
-def grazing_scene(offset, fillers, seed, size=(64, 64), mirrors=True):
+def grazing_scene(offset, fillers, seed, size=(64, 64), mirrors=True, projection=None):
     """A floor sphere, two lights, tangent spheres on the primary rays of a lattice of pixels and on the shadow rays
     of another lattice, plus `fillers` small random spheres; everything moved by `offset`.  Without `mirrors` no shape
     reflects (the candidate lists of level 6 take such scenes)."""
     ox, oy, oz = offset
     rt = RayTracer(*size)
     rt.aliasing, rt.numPasses, rt.maxDepth = ANTIALIASING_OFF, 1, 3
+    if projection is not None:
+        rt.projectionType = projection
     rt.sceneInitialize([ox, oy, oz], 256, 1000)
     rt.camInitialize(rt.target, rt.targetToScreen, rt.screenToCam)
     for pos in ((ox + 40.0, oy + 420.0, oz + 60.0), (ox - 260.0, oy + 380.0, oz - 120.0)):
@@ -178,6 +182,17 @@ def test_tangent_spheres_ordinary_coordinates(gpu):
     assert used == [0, 7]
     used, _ = check_levels(grazing_scene((0.0, 0.0, 0.0), 2300, 2, size=(48, 48), mirrors=False), (0, 7))
     assert used == [0, 7]
+
+
+def test_tangent_spheres_orthographic(gpu):
+    """The same lattice of tangent spheres on the parallel primary rays of an orthographic view: the tile lists of
+    levels 6 and 7 decide by the distance across the rays."""
+    used, want = check_levels(grazing_scene((0.0, 0.0, 0.0), 60, 9, mirrors=False, projection=ORTHOGRAPHIC), (0, 3, 6))
+    assert used == [0, 3, 6] and (want["index"] > 0).sum() > 20
+    used, _ = check_levels(grazing_scene((0.0, 0.0, 0.0), 60, 9, projection=ORTHOGRAPHIC), (0, 7))
+    assert used == [0, 7]
+    used, _ = check_levels(grazing_scene((1.6e4, 1.5e4, 1.7e4), 60, 10, mirrors=False, projection=ORTHOGRAPHIC), (0, 6))
+    assert used == [0, 6]
 
 
 def test_tangent_spheres_just_under_the_coordinate_limits(gpu):

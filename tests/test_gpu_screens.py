@@ -1,7 +1,7 @@
 """The conservative screens (single-precision per-sphere screen, two-level ball screen, per-family cone screens)
 must never change a result.  Random and adversarial sphere scenes, GPU against the CPU oracle, bit for bit, at
 every screen level (the screen_cap setting, 0..7, caps the level a job may use; 0 is the plain double-precision loop).
-Level 6 (candidate lists in LDS) takes scenes without reflecting shapes seen in perspective; the scenes of the other
+Level 6 (candidate lists in LDS) takes scenes without reflecting shapes; the scenes of the other
 tests mostly have mirrors (level 7: lists in global memory, a grid for the rays behind a mirror), so the tests at the
 end of this file run their shapes again without."""
 import numpy as np
@@ -245,11 +245,13 @@ def test_levels_are_actually_used(gpu):
     assert level(matte(large_scene(32, 2100, lights=4))) == 7   # its list tables do not fit in LDS
     assert level(matte(large_scene(32, 2100, lights=4)), 6) == 5
     assert level(matte(large_scene(33, 600, lights=3))) == 6
-    assert level(scene(11, 130, projection=ORTHOGRAPHIC)) == 3    # no camera to build tile lists around
-    assert level(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7)) == 5
+    assert level(scene(11, 130, projection=ORTHOGRAPHIC)) == 6    # tile lists of parallel rays
+    assert level(scene(11, 130, projection=ORTHOGRAPHIC), 5) == 3
+    assert level(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7)) == 7
+    assert level(large_scene(31, 1237, projection=ORTHOGRAPHIC, lights=7), 5) == 5
     far = large_scene(35, 1500, projection=ORTHOGRAPHIC, lights=7, refl=0.5, depth=3)
     far.sceneInitialize([0.0, 0.0, 0.0], 30000.0, 1000.0)
-    assert level(far) == 5
+    assert level(far) == 7 and level(far, 5) == 5
     assert level(scene(20, 100, lights=9)) == 2          # too many lights for the family tables
     assert level(scene(1, 40)) == 1                      # too few spheres for grouping
     assert level(scenes.default_scene()) == 1            # planes: per-sphere screen only
@@ -259,7 +261,7 @@ def test_levels_are_actually_used(gpu):
 
 
 
-# ---- level 6: candidate lists (scenes without reflecting shapes, perspective) -------------------------------------
+# ---- level 6: candidate lists (scenes without reflecting shapes) -------------------------------------
 
 def matte(rt):
     """The same scene with every reflectivity set to 0."""
@@ -306,6 +308,34 @@ def test_lists_shared_by_the_tiles_of_a_ticket(gpu):
         check_all_levels(rt, levels=(0, 6, 7))
     finally:
         set_diagnostic("tiles_per_ticket", old)
+
+
+def test_lists_orthographic_views(gpu):
+    """Orthographic views (mainTracing.c:410-413: every primary ray has the direction -viewDir): the tile list holds the
+    spheres whose distance from the tile's centre line, measured across the rays, is within their radius plus the tile's
+    reach.  Plain, rotated and zoomed, supersampled, with mirrors (level 7), seen from tens of thousands of units away,
+    and with view vectors that are NOT perpendicular to one another (the reference never produces such a view; the
+    library takes what it is given)."""
+    check_all_levels(scene(80, 150, projection=ORTHOGRAPHIC), levels=(0, 6, 7))
+    rt = scene(81, 180, projection=ORTHOGRAPHIC, size=(72, 40), radius=(4.0, 30.0))
+    rt.rotateView(0.5, [0.2, 1.0, 0.0])
+    rt.rotateView(-0.3, list(rt.lrVec))
+    rt.screenWidth *= 0.9
+    rt.screenHeight *= 1.1
+    check_all_levels(rt, levels=(0, 6))
+    rt.aliasing, rt.numPasses = ANTIALIASING_ON, 3
+    check_all_levels(rt, levels=(0, 6))
+    rt.aliasing, rt.numPasses = ANTIALIASING_ON, 1
+    check_all_levels(rt, levels=(0, 6))
+    check_all_levels(scene(82, 200, projection=ORTHOGRAPHIC, refl=0.6, depth=4), levels=(0, 7))
+    far = large_scene(83, 1500, projection=ORTHOGRAPHIC, lights=5, refl=0.5, depth=3)
+    far.sceneInitialize([0.0, 0.0, 0.0], 30000.0, 1000.0)
+    far.rotateView(0.7, [0.3, 1.0, 0.1])
+    check_all_levels(far, levels=(0, 7))
+    skew = scene(84, 160, projection=ORTHOGRAPHIC, size=(56, 48))
+    skew.lrVec = [1.0, 0.15, -0.3]     # neither unit length nor perpendicular to viewDir or udVec
+    skew.udVec = [0.1, 0.9, 0.2]
+    check_all_levels(skew, levels=(0, 6))
 
 
 def test_lists_lights_and_camera_inside_or_on_spheres(gpu):
