@@ -508,7 +508,8 @@ inline int packJob(const GraftScene *scene, const GraftView *view, const Setting
     bool spheresInRange = sph.size() / 4 >= 64;
     for (size_t k = 0; k < sph.size() / 4 && spheresInRange; ++k)  // (what packBallTable asks of a scene; rejects NaN)
         spheresInRange = fabs(sph[4 * k]) + fabs(sph[4 * k + 1]) + fabs(sph[4 * k + 2]) + sqrt(sph[4 * k + 3]) < kGroupScale;
-    if (wantGroups && screenCap >= 6 && nL <= 7 && scale < kGroupScale && spheresInRange) {
+    // (up to 31 lights: the lists need no table per light in LDS, only an index word per sphere and light)
+    if (wantGroups && screenCap >= 6 && nL <= 31 && scale < kGroupScale && spheresInRange) {
         if (cache.groupSize != groupSize || cache.sph != sph) cache.reset(sph, groupSize);
         cache.makeRoom(apexes.size());
         std::vector<float> image;

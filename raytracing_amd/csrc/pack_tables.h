@@ -585,7 +585,7 @@ inline void packOrthoTable(const std::vector<double> &sph, const double centre[3
     const int n = (int)(sph.size() / 4);
     const double eBound = 1e-13 * (4 * scale) * (4 * scale);
     const double margin = 1.01 * sqrt(eBound) + 1e-9 * scale;
-    const double roundOff = 4 * 5.9604644775390625e-08 * scale;  // (three coordinates rounded to float, and R itself)
+    const double roundOff = 8 * 5.9604644775390625e-08 * scale;  // (three coordinates of up to 2 * scale rounded to float, and R itself)
     std::vector<double> q(3 * (size_t)n), R(n);
     for (int k = 0; k < n; ++k) {
         const double *c = &sph[4 * (size_t)k];

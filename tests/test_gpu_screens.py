@@ -163,7 +163,9 @@ def test_large_coordinates_fall_back(gpu):
 
 def test_many_lights(gpu):
     check_all_levels(scene(19, 100, lights=7))
-    check_all_levels(scene(20, 100, lights=9))  # more families than the cone tables support: ball screen
+    check_all_levels(scene(20, 100, lights=9))  # more families than the cone tables support: ball screen, or lists
+    check_all_levels(scene(22, 140, lights=31, size=(40, 40)), levels=(0, 2, 6))
+    check_all_levels(scene(23, 140, lights=19, size=(40, 40), refl=0.5, depth=3), levels=(0, 7))
 
 
 def test_transparent_with_many_spheres(gpu):
@@ -252,7 +254,8 @@ def test_levels_are_actually_used(gpu):
     far = large_scene(35, 1500, projection=ORTHOGRAPHIC, lights=7, refl=0.5, depth=3)
     far.sceneInitialize([0.0, 0.0, 0.0], 30000.0, 1000.0)
     assert level(far) == 7 and level(far, 5) == 5
-    assert level(scene(20, 100, lights=9)) == 2          # too many lights for the family tables
+    assert level(scene(20, 100, lights=9)) == 6 and level(scene(20, 100, lights=9), 5) == 2   # too many lights for the family tables, not for the lists
+    assert level(scene(20, 100, lights=32)) == 2
     assert level(scene(1, 40)) == 1                      # too few spheres for grouping
     assert level(scenes.default_scene()) == 1            # planes: per-sphere screen only
     rt = scene(21, 90)
