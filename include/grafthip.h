@@ -140,7 +140,7 @@ enum {
     GRAFT_DIAG_TILES_PER_TICKET = 2, /* 8x8 tiles a wave draws from the ticket counters at once: 0 = chosen per launch */
     GRAFT_DIAG_TABLE_BUILDS = 4,     /* read-only: screen tables built so far (shows what a re-render re-used) */
     GRAFT_DIAG_RESERVED_CUS = 5,     /* CUs a trace's persistent grid leaves free, 0..128; default 0 (graftRenderFrameMulti uses at least 4) */
-    GRAFT_DIAG_COPY_PIECE_KB = 6,    /* graftRenderRows traces and copies a large frame in pieces of about this many KiB (at most 16 pieces); 0 = one piece; default 65536 */
+    GRAFT_DIAG_COPY_PIECE_KB = 6,    /* graftRenderRows traces and copies a large frame in pieces of about this many KiB (at most 16 pieces); 0 = one piece; default -1 = chosen per frame */
     GRAFT_DIAG_EMULATED_DEVICES = 7  /* tests on a machine with too few GPUs: with n > 0 graftInitDevices may bind up to n devices, device d
                                       * standing for GPU d mod (GPUs present) with streams, buffers and a job of its own; pieces then reach the
                                       * root by device-to-device copies instead of RCCL; default 0 */
@@ -206,7 +206,7 @@ GRAFT_API int graftSynchronize(void);
  * frame buffers (grow-only), and the packed job -- a call whose scene, view and settings equal the previous call's
  * byte for byte packs and uploads nothing; one that differs re-packs into the same device block, re-using the screen
  * tables whose inputs did not change (a key press that toggles anti-aliasing or depth rebuilds none, one that turns
- * the view rebuilds the camera's only).  A frame of more than 128 MiB is traced in up to 16 pieces of rows, each
+ * the view rebuilds the camera's only).  A frame of more than about 100 MiB is traced in up to 16 pieces of rows, each
  * copied to the host (on a stream of its own) while the next ones are traced; give it a page-locked frameHost
  * (graftHostAlloc), or the copies cannot overlap anything. */
 GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, int row0, int nRows, int format,

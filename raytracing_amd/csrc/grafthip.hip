@@ -1200,7 +1200,7 @@ GRAFT_API int graftDiagnosticSet(int which, int value) {
             gSettings.reservedCUs = value;
             return GRAFT_OK;
         case GRAFT_DIAG_COPY_PIECE_KB:
-            if (value < 0) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: copy pieces of %d KiB", value);
+            if (value < -1) return fail(GRAFT_ERR_ARG, "graftDiagnosticSet: copy pieces of %d KiB", value);
             gSettings.copyPieceKB = value;
             return GRAFT_OK;
         case GRAFT_DIAG_EMULATED_DEVICES:
@@ -1466,12 +1466,21 @@ GRAFT_API int graftRenderRows(const GraftScene *scene, const GraftView *view, in
     }
     // A large frame is traced in pieces of rows, and every finished piece leaves for the host (on the copy stream,
     // behind an event) while the next ones are traced: the copy of a 16384 x 16384 frame takes about as long as its
-    // trace, and one after the other they would double the call.  Pieces of about copyPieceKB of frame each (0: the
-    // whole band in one piece), at most 16; small frames are one piece, whose launch and copy are as before.
+    // trace, and one after the other they would double the call.  How many pieces: every piece is a launch of its own
+    // (measured: about 0.8 ms of a 16384-wide frame each) and the copy of the last one is not hidden, so a frame whose
+    // copy is short beside its trace wants about sqrt(copy time / 0.8 ms) pieces -- sqrt(bytes / 48 MiB) at the 55 GB/s
+    // of the link --, while a frame whose copy outlasts its trace wants the copy to start as early as possible: at
+    // least one piece per 256 MiB.  At most 16; small frames are one piece, whose launch and copy are as before.
+    // copyPieceKB > 0 forces pieces of about that size, 0 one piece.
     const int nCols = job->P.nCols;
     int pieces = 1;
     if (gSettings.copyPieceKB > 0) {
         const size_t want = frameBytes / ((size_t)gSettings.copyPieceKB << 10);
+        pieces = (int)(want < 1 ? 1 : want > 16 ? 16 : want);
+    } else if (gSettings.copyPieceKB < 0) {
+        const double few = sqrt((double)frameBytes / (double)((size_t)48 << 20));
+        const size_t many = frameBytes >> 28;
+        const size_t want = (size_t)(few + 0.5) > many ? (size_t)(few + 0.5) : many;
         pieces = (int)(want < 1 ? 1 : want > 16 ? 16 : want);
     }
     const int tileRows = (int)(((long long)nRows + kTile - 1) / kTile);

@@ -23,7 +23,7 @@ struct Settings {
     int groupSize = 0;       // spheres per group of the two-level screens, 0 = chosen per scene
     int tilesPerTicket = 0;  // tiles a wave draws at once, 0 = chosen per launch
     int reservedCUs = 0;     // CUs a trace's persistent grid leaves free (for transfer kernels running beside it)
-    int copyPieceKB = 65536; // graftRenderRows: a frame leaves for the host in pieces of about this size (0: in one piece)
+    int copyPieceKB = -1;    // graftRenderRows: a frame leaves for the host in pieces of about this size (0: in one piece, -1: chosen per frame)
 };
 
 struct PackedJob {
