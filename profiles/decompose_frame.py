@@ -1,28 +1,30 @@
-"""Where the frame time of the 1024-sphere workload goes: the same frame traced with fewer lights, and with the scene
-moved out of sight (every tile list empty), on a quarter of the rows.
-    python profiles/cfg4_decompose.py"""
+"""Where the frame time of a workload goes: the same frame traced with fewer lights, and with the scene moved out of
+sight (every tile list empty), on the middle rows of the frame (at most 4096).
+    python profiles/decompose_frame.py [cfg4|cfg3|cfg5]"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracing_amd
 from raytracing_amd import scenes
 from raytracing_amd.tracer import GRAFT_OUT_F32_RGBA
 raytracing_amd.init(0)
+NAME = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 ROWS = 4096
 
 
 def run(tag, change):
-    rt = scenes.workload("cfg4")
+    rt = scenes.workload(NAME)
     change(rt)
     job = rt.create_job()
-    buf = torch.empty((ROWS, job.nCols, 4), dtype=torch.float32, device="cuda")
+    rows = min(ROWS, job.nRows)
+    buf = torch.empty((rows, job.nCols, 4), dtype=torch.float32, device="cuda")
     cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
     stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); st = stream.cuda_stream
-    row0 = (job.nRows - ROWS) // 2
-    job.trace(row0, ROWS, GRAFT_OUT_F32_RGBA, buf.data_ptr(), None, cnt.data_ptr(), st); torch.cuda.synchronize()
+    row0 = (job.nRows - rows) // 2
+    job.trace(row0, rows, GRAFT_OUT_F32_RGBA, buf.data_ptr(), None, cnt.data_ptr(), st); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(3):
-        job.trace(row0, ROWS, GRAFT_OUT_F32_RGBA, buf.data_ptr(), None, None, st)
+        job.trace(row0, rows, GRAFT_OUT_F32_RGBA, buf.data_ptr(), None, None, st)
     b.record(); torch.cuda.synchronize()
     c = cnt.tolist()
     print("%-28s level %d  %.3f ms  queries made %.4g (reference %.4g)" % (tag, job.screen_level(), a.elapsed_time(b) / 3, c[2], c[0]), flush=True)
