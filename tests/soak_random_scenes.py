@@ -2,7 +2,9 @@
 1 to 9 lights with and without avoid lists, mirrors, transparent shapes, depths 1 to 6, supersampling on and off --
 through assert_parity: frames and index masks bit for bit, the reference's ray and test counts, and the number of
 queries the library made against the oracle's prediction.
-    python tests/soak_random_scenes.py [count] [first seed]"""
+    python tests/soak_random_scenes.py [count] [first seed] [wide]
+"wide": frames of up to 333 x 72 pixels (dozens of tiles per row of tiles, widths that are no multiple of the tile) and a
+random ticket size, so that tile lists shared by the tiles of a ticket and tickets that straddle rows of tiles are met."""
 import os
 import sys
 
@@ -20,13 +22,17 @@ import test_gpu_screens as ts
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 raytracing_amd.init(0)
 for seed in range(first, first + count):
     rng = scenes.SplitMix64(0x50A70000 + seed)
     pick = lambda *xs: xs[int(rng.uniform(0, len(xs) - 1e-9))]  # noqa: E731
     n = pick(3, 12, 31, 32, 40, 90, 300, 1200)
     lights = pick(1, 2, 3, 4, 5, 7, 9)
-    rt = ts.scene(1000 + seed, n, size=(48, 40), lights=lights, radius=pick((2.0, 9.0), (5.0, 40.0), (20.0, 120.0)),
+    size = (pick(96, 200, 333, 130), pick(40, 72, 17)) if wide else (48, 40)
+    if wide:
+        set_diagnostic("tiles_per_ticket", pick(0, 0, 2, 3, 5, 8))
+    rt = ts.scene(1000 + seed, n, size=size, lights=lights, radius=pick((2.0, 9.0), (5.0, 40.0), (20.0, 120.0)),
                   box=pick(150.0, 400.0), refl=pick(0.0, 0.4, 0.9), depth=pick(1, 2, 3, 6),
                   projection=pick(PERSPECTIVE, PERSPECTIVE, ORTHOGRAPHIC), passes=pick(0, 0, 2, 3))
     k = rt.numShapes
@@ -46,4 +52,5 @@ for seed in range(first, first + count):
     print("seed %d ok: %d shapes, %d lights, depth %d, queries made %d of %d" % (
         seed, rt.numShapes, rt.numLights, rt.maxDepth, rt.last_rays_traced, rt.last_counters[0]), flush=True)
 set_diagnostic("screen_cap", 7)
+set_diagnostic("tiles_per_ticket", 0)
 print("soak ok: %d scenes" % count)
