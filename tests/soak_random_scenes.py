@@ -4,7 +4,8 @@ through assert_parity: frames and index masks bit for bit, the reference's ray a
 queries the library made against the oracle's prediction.
     python tests/soak_random_scenes.py [count] [first seed] [wide]
 "wide": frames of up to 333 x 72 pixels (dozens of tiles per row of tiles, widths that are no multiple of the tile) and a
-random ticket size, so that tile lists shared by the tiles of a ticket and tickets that straddle rows of tiles are met."""
+random ticket size, so that tile lists shared by the tiles of a ticket and tickets that straddle rows of tiles are met,
+and up to 32 lights (31 is the most that candidate lists take)."""
 import os
 import sys
 
@@ -28,7 +29,7 @@ for seed in range(first, first + count):
     rng = scenes.SplitMix64(0x50A70000 + seed)
     pick = lambda *xs: xs[int(rng.uniform(0, len(xs) - 1e-9))]  # noqa: E731
     n = pick(3, 12, 31, 32, 40, 90, 300, 1200)
-    lights = pick(1, 2, 3, 4, 5, 7, 9)
+    lights = pick(1, 2, 3, 5, 9, 17, 31, 32) if wide else pick(1, 2, 3, 4, 5, 7, 9)
     size = (pick(96, 200, 333, 130), pick(40, 72, 17)) if wide else (48, 40)
     if wide:
         set_diagnostic("tiles_per_ticket", pick(0, 0, 2, 3, 5, 8))
