@@ -1045,13 +1045,21 @@ __device__ __forceinline__ int buildTileList(const TraceParams &P, ConstDoubles 
 
 // Closest hit among the spheres of the lane's list: `len` sphere numbers from chunk `pos` on (a chunk is four 16-bit
 // numbers, fetched with one read and used up over four trips) -- of the list pool, or, `tile`, of LDS, where the
-// waves' tile lists are (at level 6 the pool is in LDS too and `pos` counts from its start either way).  One candidate is
-// parked per lane and the exact test runs, for every lane that has one parked, when some lane needs the slot again
-// or has reached the end of its list -- one code site, shared by lanes whose lists differ.  Spheres are met out of
-// index order: see closestHitGrouped for why the winner does not depend on it.
+// waves' tile lists are (at level 6 the pool is in LDS too and `pos` counts from its start either way).  Lanes of a
+// wave follow different lists through one code site.  Spheres are met out of index order: see closestHitGrouped for
+// why the winner does not depend on it.
 // `self` >= 0: the sphere a shadow ray starts on, which its list leaves out.  The ray starts a hair outside it; when
 // it moves away from the centre (the light lies in front of the surface) both roots are negative and the sphere is
 // done with (the first clause of exactSphereLazy: shapes.c:62-66 reports a miss); otherwise it is the first candidate.
+//
+// !GLOBAL (everything in LDS): two loops that take turns.  The screen loop runs the single-precision screen of
+// closestHitScreened over the lists and keeps the numbers of the spheres that pass, up to four per lane in one 64-bit
+// register; when some lane holds four, or every list has ended, the exact loop takes them one per trip -- the lanes'
+// first survivors together, then their second ones.  Both loops have one exit, decided by ballots, and change their
+// state in place (loops with several exits cost a dozen register copies a trip).
+// GLOBAL (the exact doubles come from global memory): one loop; a sphere that passes the screen is parked with its
+// doubles already requested, and the exact test runs, for every lane that has one parked, when some lane needs the
+// slot again or has reached the end of its list -- the request is a trip old by then.
 template <bool GLOBAL>
 __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx, double sy, double sz, double dx, double dy,
                                                 double dz, int pos, int len, bool tile, int self, float negThreshold, Hit &h) {
@@ -1060,7 +1068,7 @@ __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx,
     const unsigned long long *pool = (const unsigned long long *)((GLOBAL ? (const char *)P.geomF : (const char *)ldsGeom) + P.listPoolOff);
     const unsigned long long *tiles = (const unsigned long long *)ldsGeom;
     unsigned long long chunk = 0;
-    int trip = 0;
+    int trip = 0;  // (the same for all lanes)
     Best closest = {0, -1, -1};
     const double slackBase = fabs(sx) + fabs(sy) + fabs(sz);
     const double dd = dx * dx + dy * dy + dz * dz;
@@ -1076,40 +1084,77 @@ __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx,
         const double w = (vx * vx + vy * vy + vz * vz) - pendingGeom.w;
         if (!(b > 0 && w > b * b * 8.9e-16)) pending = self;
     }
-    while (__ballot(len > 0 || pending >= 0)) {
-        int j = -1;
-        if ((trip & 3) == 0 && len > 0) {  // (the trip count is the same for all lanes)
-            chunk = GLOBAL && tile ? tiles[pos] : pool[pos];
-            ++pos;
-        }
-        ++trip;
-        if (len > 0) {
-            const int k = (int)(chunk & 0xffffu);
-            chunk >>= 16;
-            const float4v e = aos[k];
-            // single-precision screen (closestHitScreened's arithmetic): below the threshold = exact discriminant negative
-            const float vx = sxf - e.x, vy = syf - e.y, vz = szf - e.z;
-            float b = vx * dxf;
-            b = __builtin_fmaf(vy, dyf, b);
-            b = __builtin_fmaf(vz, dzf, b);
-            float vv = vx * vx;
-            vv = __builtin_fmaf(vy, vy, vv);
-            vv = __builtin_fmaf(vz, vz, vv);
-            if (!(__builtin_fmaf(b, b, e.w - vv) < negThreshold)) j = k;
-        }
-        --len;
-        if (__ballot(pending >= 0 && (j >= 0 || len <= 0))) {
-            if (pending >= 0) {
+    // single-precision screen (closestHitScreened's arithmetic): below the threshold = exact discriminant negative
+    auto passes = [&](const float4v e) {
+        const float vx = sxf - e.x, vy = syf - e.y, vz = szf - e.z;
+        float b = vx * dxf;
+        b = __builtin_fmaf(vy, dyf, b);
+        b = __builtin_fmaf(vz, dzf, b);
+        float vv = vx * vx;
+        vv = __builtin_fmaf(vy, vy, vv);
+        vv = __builtin_fmaf(vz, vz, vv);
+        return !(__builtin_fmaf(b, b, e.w - vv) < negThreshold);
+    };
+    if constexpr (!GLOBAL) {
+        // numbers + 1 of the spheres that passed the screen and wait for the exact test, 16 bits each, the latest lowest
+        unsigned long long kept = pending >= 0 ? (unsigned long long)(pending + 1) : 0;
+        for (;;) {
+            bool screening = (__ballot(len > 0) != 0) & (__ballot((unsigned)(kept >> 32) > 0xffffu) == 0);
+            while (screening) {
+                if (len > 0) {
+                    if ((trip & 3) == 0) {
+                        chunk = pool[pos];
+                        ++pos;
+                    }
+                    const int k = (int)(chunk & 0xffffu);
+                    chunk >>= 16;
+                    if (passes(aos[k])) kept = (kept << 16) | (unsigned)(k + 1);
+                }
+                trip = __builtin_amdgcn_readfirstlane(trip + 1);
+                --len;
+                screening = (__ballot(len > 0) != 0) & (__ballot((unsigned)(kept >> 32) > 0xffffu) == 0);
+            }
+            bool testing = __ballot(kept != 0) != 0;
+            while (testing) {
 #ifdef GRAFT_STAMPS
                 if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 10, 1ull);
 #endif
-                exactSphereLazy(pendingGeom, pending, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
-                pending = -1;
+                if (kept != 0) {
+                    const int k = (int)(kept & 0xffffu) - 1;
+                    kept >>= 16;
+                    exactSphereLazy(geom[k], k, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
+                }
+                testing = __ballot(kept != 0) != 0;
             }
+            if (__ballot(len > 0) == 0) break;
         }
-        if (j >= 0) {
-            pending = j;
-            pendingGeom = geom[j];
+    } else {
+        while (__ballot(len > 0 || pending >= 0)) {
+            int j = -1;
+            if ((trip & 3) == 0 && len > 0) {
+                chunk = tile ? tiles[pos] : pool[pos];
+                ++pos;
+            }
+            ++trip;
+            if (len > 0) {
+                const int k = (int)(chunk & 0xffffu);
+                chunk >>= 16;
+                if (passes(aos[k])) j = k;
+            }
+            --len;
+            if (__ballot(pending >= 0 && (j >= 0 || len <= 0))) {
+                if (pending >= 0) {
+#ifdef GRAFT_STAMPS
+                    if (P.counters && lane64() == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 10, 1ull);
+#endif
+                    exactSphereLazy(pendingGeom, pending, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
+                    pending = -1;
+                }
+            }
+            if (j >= 0) {
+                pending = j;
+                pendingGeom = geom[j];
+            }
         }
     }
     finishBest(closest, sx, sy, sz, dx, dy, dz, h);

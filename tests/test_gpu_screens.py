@@ -389,6 +389,24 @@ def test_lists_tiny_giant_and_overlapping_spheres(gpu):
     check_all_levels(rt, levels=(0, 6))
 
 
+def test_lists_more_survivors_than_one_round_holds(gpu):
+    """The list walk keeps up to four spheres that passed the single-precision screen before a round of exact tests;
+    rays through a row of fourteen spheres lined up behind one another along the view (and, seen from a light placed
+    on that line, along the shadow rays) pass the screen of all of them: several rounds per ray, lanes whose lists end
+    early beside lanes with a dozen survivors.  Nested and equal spheres among them (ties go to the lower index)."""
+    rt = matte(scene(65, 60, size=(56, 48), lights=2, radius=(3.0, 10.0)))
+    k = rt.numShapes
+    for i in range(14):
+        r = [30.0, 30.0, 18.0, 40.0, 30.0][i % 5]
+        rt.sphereSetup(r, [4.0 * (i % 3), -3.0 * (i % 2), 40.0 + 35.0 * i], k + i, [.2 + .05 * i, .5, .9 - .05 * i],
+                       0.0, 0.1, 1.0, 0.0)
+    rt.numShapes = k + 14
+    rt.lights[1].loc = [3.0, -1.0, -200.0]          # on the line of the row: its shadow rays run along it
+    check_all_levels(rt, levels=(0, 6, 7))
+    rt.aliasing, rt.numPasses = ANTIALIASING_ON, 2
+    check_all_levels(rt, levels=(0, 6))
+
+
 def test_lists_tile_list_overflow_and_wide_views(gpu):
     """More spheres in a tile's cone than its list holds (a small frame of many spheres): the tile falls back to the
     list of all spheres; and a view so wide that a tile has no usable bounding cone."""
