@@ -69,8 +69,12 @@ namespace {
 // MIRRORS: some shape reflects (or is transparent): a shaded hit may have children, so the lane keeps a stack of
 // levels.  Without it (the reference only recurses `if (reflectivity > 0 && shouldReflect == 1)`, mainTracing.c:330,
 // or for a transparent shape, :347) a ray's value is its hit's own shading and goes straight into the pixel's sum.
-template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS, bool MIRRORS = true>
+// EXTRAS = false: a launch that asks for neither the index mask nor the ray counts (what launchRays itself produces is
+// the frame alone); the mask ray, the per-lane counts and their registers are compiled out.
+template <int AVOID, bool LDSGEOM, int SCREEN, bool EXACTLDS, bool TRANSP, bool MANYCURSORS, bool MIRRORS = true, bool EXTRAS = true>
 __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) {
+    int32_t *const hitIndexOut = EXTRAS ? P.hitIndex : nullptr;
+    unsigned long long *const countersOut = EXTRAS ? P.counters : nullptr;
     static_assert(MIRRORS || !TRANSP, "the tree walk needs the stack");
     constexpr bool LISTS = SCREEN == 6 || SCREEN == 7;   // candidate lists
     constexpr bool GLOBALLISTS = SCREEN == 7;             // ... read from global memory
@@ -97,7 +101,16 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
     }
     const int lane = threadIdx.x & 63;
     const int lx = lane & (kTile - 1), ly = lane >> 3;
-    const int nSamples = P.aliasing ? P.numPasses * P.numPasses : 1;
+    // Kernels that draw single tiles from one counter and have candidate lists are only launched for supersampled frames
+    // whose table of sample scale factors is in LDS (launchTrace): both are known when they are compiled.
+#ifdef GRAFT_TABLE_AT_RUN_TIME  // (A/B builds: asked per launch, as in the other kernels)
+    constexpr bool kTabled = false;
+#else
+    constexpr bool kTabled = SCREEN >= 6 && GRAFT_SAMPLE_TABLE && !MANYCURSORS;
+#endif
+    const bool aliasing = kTabled || P.aliasing;
+    const bool tabled = kTabled || (SCREEN >= 6 && GRAFT_SAMPLE_TABLE && !MANYCURSORS && P.sampleTableOff >= 0);
+    const int nSamples = aliasing ? P.numPasses * P.numPasses : 1;
     // Ray statistics (GraftCounters): the reference's closest-hit queries and ray-shape evaluations for these pixels,
     // and the queries answered here (shadow rays whose answer cannot matter are not shot, see the lights' loop).  Per
     // lane and tile three small counts -- queries other than shadow rays (the reference makes exactly those too), shaded
@@ -284,8 +297,8 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             const int ix0 = tx * kTile, ix1 = min(lastTx * kTile + kTile, P.nCols) - 1;
             const int iy0 = P.row0 + ty * kTile, iy1 = P.row0 + min(ty * kTile + kTile, P.bandRows) - 1;
             // samples lie at the pixel's offsets plus 0 (the mask ray) .. numPasses sub-steps (mainTracing.c:405-406)
-            const double spanX = P.aliasing ? cam[CAM_SUBX] * (double)P.numPasses : 0.0;
-            const double spanY = P.aliasing ? cam[CAM_SUBY] * (double)P.numPasses : 0.0;
+            const double spanX = aliasing ? cam[CAM_SUBX] * (double)P.numPasses : 0.0;
+            const double spanY = aliasing ? cam[CAM_SUBY] * (double)P.numPasses : 0.0;
             const int found = buildTileList<GLOBALLISTS>(P, cam, P.colOff[ix0] + fmin(spanX, 0.0), P.colOff[ix1] + fmax(spanX, 0.0),
                                             P.rowOff[iy0] + fmin(spanY, 0.0), P.rowOff[iy1] + fmax(spanY, 0.0),
                                             (unsigned short *)((char *)ldsGeom + P.listTileOff) + (threadIdx.x >> 6) * kTileListCap);
@@ -293,7 +306,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             // Supersampling: the scale factor of a sample's first getNewPoint step (mainTracing.c:405, :107-108: a
             // division and a square root) depends on (column, k) only, that of the second (:406) on (row, l): all
             // 16 numPasses of them are worked out once per tile, one per lane, and read back per sample.
-            if (GRAFT_SAMPLE_TABLE && !MANYCURSORS && P.sampleTableOff >= 0) {
+            if (tabled) {
                 double *tab = (double *)((char *)ldsGeom + P.sampleTableOff) + (threadIdx.x >> 6) * 16 * P.numPasses;
                 if (lane < kTile * P.numPasses) {
                     const int c = (int)__umulhi((unsigned)lane, P.numPassesRecip), k = lane - c * P.numPasses;
@@ -327,10 +340,10 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
             // the screen point of sample s (k = s / numPasses outer, l inner: mainTracing.c:401-408)
             auto samplePoint = [&](int s, double out[3]) {
                 double xo = colI, yo = rowJ;
-                if (P.aliasing) {
+                if (aliasing) {
                     // k = s / numPasses by a multiplication (exact below 2^20 samples, host_job.h)
                     const int k = (int)__umulhi((unsigned)s, P.numPassesRecip), l = s - k * P.numPasses;
-                    if (LISTS && GRAFT_SAMPLE_TABLE && !MANYCURSORS && P.sampleTableOff >= 0) {  // the two steps' scale factors from the tile's table
+                    if (tabled) {  // the two steps' scale factors from the tile's table
                         const double *tab = (const double *)((const char *)ldsGeom + P.sampleTableOff) + (threadIdx.x >> 6) * 16 * P.numPasses;
                         const double scaleX = tab[lx * P.numPasses + k], scaleY = tab[(kTile + ly) * P.numPasses + l];
                         for (int c = 0; c < 3; ++c) {
@@ -389,15 +402,15 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 // No sphere can be met by any primary ray of this tile (mask ray included): every sample is the
                 // background colour (mainTracing.c:314-317), summed as the reference sums it (:419).  The queries
                 // count as answered.
-                const unsigned queries = (unsigned)nSamples + (P.hitIndex && P.aliasing ? 1u : 0u);
+                const unsigned queries = (unsigned)nSamples + (hitIndexOut && aliasing ? 1u : 0u);
                 nOther += queries;
                 nAnswered += queries;
-                if (P.aliasing)
+                if (aliasing)
                     for (int s = 0; s < nSamples; ++s) {
                         acc[0] = acc[0] + cam[CAM_BACKGROUND]; acc[1] = acc[1] + cam[CAM_BACKGROUND + 1]; acc[2] = acc[2] + cam[CAM_BACKGROUND + 2];
                     }
                 mode = M_DONE;
-            } else if (P.hitIndex && (P.aliasing || traceNothing)) {  // mask ray = the anti-aliasing-off ray of this pixel
+            } else if (hitIndexOut && (aliasing || traceNothing)) {  // mask ray = the anti-aliasing-off ray of this pixel
                 primaryRay(P, colI, rowJ, o, d);
                 mode = M_INDEX;
             } else if (traceNothing) {
@@ -406,7 +419,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 startSample(0);
             }
             if (traceNothing) {
-                if (P.aliasing) { acc[0] = acc[0] + 0.0; acc[1] = acc[1] + 0.0; acc[2] = acc[2] + 0.0; }
+                if (aliasing) { acc[0] = acc[0] + 0.0; acc[1] = acc[1] + 0.0; acc[2] = acc[2] + 0.0; }
                 else acc[0] = acc[1] = acc[2] = 0;
             }
 
@@ -435,7 +448,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                 unsigned long long stampMark = clock64();
                 auto stampStage = [&](int which) {
                     const unsigned long long now = clock64();
-                    if (P.counters && lane == (int)__builtin_ctzll(__ballot(1))) atomicAdd(P.counters + 17 + which, now - stampMark);
+                    if (countersOut && lane == (int)__builtin_ctzll(__ballot(1))) atomicAdd(countersOut + 17 + which, now - stampMark);
                     stampMark = now;
                 };
 #define GRAFT_STAGE(which) stampStage(which)
@@ -450,7 +463,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                     if (traceNothing) mode = M_DONE;
                     else next = NEXT_SAMPLE;
                 } else if (mode == M_RADIANCE) {
-                    if (depth == 0 && sample == 0 && !P.aliasing) firstIdx = h.idx;
+                    if (depth == 0 && sample == 0 && !aliasing) firstIdx = h.idx;
                     if (h.idx < 0) {  // mainTracing.c:314-317
                         v[0] = cam[CAM_BACKGROUND]; v[1] = cam[CAM_BACKGROUND + 1]; v[2] = cam[CAM_BACKGROUND + 2];
                         unwind = true;
@@ -664,7 +677,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
                         }
                     }
                     if (!launched) {
-                        if (P.aliasing) {  // mainTracing.c:419
+                        if (aliasing) {  // mainTracing.c:419
                             acc[0] = acc[0] + v[0]; acc[1] = acc[1] + v[1]; acc[2] = acc[2] + v[2];
                         } else {
                             acc[0] = v[0]; acc[1] = v[1]; acc[2] = v[2];
@@ -715,14 +728,14 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
 #ifdef GRAFT_STAMPS
             if (loopLeader) stampLoop += clock64() - stampLoop0;
 #endif
-            if (P.aliasing) {  // mainTracing.c:422-423: counter == numPasses^2
+            if (aliasing) {  // mainTracing.c:422-423: counter == numPasses^2
                 const double n = (double)nSamples;
                 acc[0] = acc[0] / n; acc[1] = acc[1] / n; acc[2] = acc[2] / n;
             }
-            if (P.hitIndex) P.hitIndex[pixel] = firstIdx;
+            if (hitIndexOut) hitIndexOut[pixel] = firstIdx;
             storeColor(pixel, acc);
         }
-        if (P.counters) {  // (all lanes: the shuffles read lanes outside the frame too, whose counts are zero)
+        if (countersOut) {  // (all lanes: the shuffles read lanes outside the frame too, whose counts are zero)
             unsigned long long other = nOther, hits = nHits, answered = nAnswered;
             for (int off = 32; off > 0; off >>= 1) {
                 other += __shfl_down(other, off);
@@ -739,7 +752,7 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
         nOther = nHits = nAnswered = 0;
         ++tile;
     }
-    if (P.counters) {
+    if (countersOut) {
         for (int off = 32; off > 0; off >>= 1) {
 #ifdef GRAFT_STAMPS
             stampHit += __shfl_down(stampHit, off);
@@ -748,15 +761,15 @@ __global__ void __launch_bounds__(kLargeBlock) traceKernel(const TraceParams P) 
 #endif
         }
         if (lane == 0) {
-            atomicAdd(P.counters, rayCount);
-            atomicAdd(P.counters + 1, testCount);
-            atomicAdd(P.counters + 2, tracedCount);
+            atomicAdd(countersOut, rayCount);
+            atomicAdd(countersOut + 1, testCount);
+            atomicAdd(countersOut + 2, tracedCount);
 #ifdef GRAFT_STAMPS
-            atomicAdd(P.counters + 4, (unsigned long long)(clock64() - stampBegin));
-            atomicAdd(P.counters + 5, stampHit);
-            atomicAdd(P.counters + 6, stampRounds);
-            atomicAdd(P.counters + 7, 1ull);
-            atomicAdd(P.counters + 8, stampLoop);
+            atomicAdd(countersOut + 4, (unsigned long long)(clock64() - stampBegin));
+            atomicAdd(countersOut + 5, stampHit);
+            atomicAdd(countersOut + 6, stampRounds);
+            atomicAdd(countersOut + 7, 1ull);
+            atomicAdd(countersOut + 8, stampLoop);
 #endif
         }
     }
@@ -904,7 +917,13 @@ typedef void (*TraceFn)(const TraceParams);
 // (GRAFT_DEV_KERNELS: a development build that only holds the kernels of the measured workloads -- seconds to
 // compile instead of minutes; every other job is refused.)
 template <int A, bool M>
-TraceFn pickKernelA(bool lds, int screen, bool exactLds, bool mirrors) {
+TraceFn pickKernelA(bool lds, int screen, bool exactLds, bool mirrors, bool extras) {
+#if !defined(GRAFT_STAMPS) && !defined(GRAFT_NO_PLAIN_KERNELS)
+    // (the kernels without mask and counts: candidate lists, lights that avoid nothing, no mirrors -- the kernels with
+    // mirrors sit at their register cap, and theirs came out 4 % slower than the ones they would replace)
+    if (A == 0 && lds && !extras && !mirrors && screen == 6) return traceKernel<0, true, 6, false, false, M, false, false>;
+    if (A == 0 && lds && !extras && !mirrors && screen == 7) return traceKernel<0, true, 7, false, false, M, false, false>;
+#endif
 #ifdef GRAFT_DEV_KERNELS
     if (A != 0 || !lds) return nullptr;
     if (screen == 7) return mirrors ? traceKernel<0, true, 7, false, false, M, true> : traceKernel<0, true, 7, false, false, M, false>;
@@ -930,20 +949,20 @@ TraceFn pickKernelA(bool lds, int screen, bool exactLds, bool mirrors) {
 // Scenes with a transparent shape run the tree-walk kernels, built only for the general avoid mode, screen
 // levels 0 and 1, and exact doubles in global memory (the jobs are normalised to that in packJob).
 template <bool M>
-TraceFn pickKernelM(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool mirrors) {
+TraceFn pickKernelM(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool mirrors, bool extras) {
 #ifndef GRAFT_DEV_KERNELS
     if (transp) {
         if (lds) return screen ? traceKernel<2, true, 1, false, true, M> : traceKernel<2, true, 0, false, true, M>;
         return screen ? traceKernel<2, false, 1, false, true, M> : traceKernel<2, false, 0, false, true, M>;
     }
 #endif
-    return avoidMode == 0 ? pickKernelA<0, M>(lds, screen, exactLds, mirrors)
-         : avoidMode == 1 ? pickKernelA<1, M>(lds, screen, exactLds, mirrors) : pickKernelA<2, M>(lds, screen, exactLds, mirrors);
+    return avoidMode == 0 ? pickKernelA<0, M>(lds, screen, exactLds, mirrors, extras)
+         : avoidMode == 1 ? pickKernelA<1, M>(lds, screen, exactLds, mirrors, extras) : pickKernelA<2, M>(lds, screen, exactLds, mirrors, extras);
 }
 
-TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool mirrors, bool manyCursors) {
-    return manyCursors ? pickKernelM<true>(avoidMode, lds, screen, exactLds, transp, mirrors)
-                       : pickKernelM<false>(avoidMode, lds, screen, exactLds, transp, mirrors);
+TraceFn pickKernel(int avoidMode, bool lds, int screen, bool exactLds, bool transp, bool mirrors, bool manyCursors, bool extras) {
+    return manyCursors ? pickKernelM<true>(avoidMode, lds, screen, exactLds, transp, mirrors, extras)
+                       : pickKernelM<false>(avoidMode, lds, screen, exactLds, transp, mirrors, extras);
 }
 
 }  // namespace
@@ -1084,8 +1103,11 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     const int wavesPerBlock = job->block / 64;
     // cheap tiles (few samples per pixel) are drawn several at a time and from several counters
     const int samples = P.aliasing ? P.numPasses * P.numPasses : 1;
-    const bool manyCursors = samples < 4;
-    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, job->mirrors, manyCursors);
+    // (... and so are supersampled frames with candidate lists whose table of sample scale factors found no room in LDS
+    // or would be too long: the single-counter list kernels are compiled for frames that have one)
+    const bool manyCursors = samples < 4 || (job->screen >= 6 && P.sampleTableOff < 0);
+    TraceFn fn = pickKernel(job->avoidMode, job->lds, job->screen, job->exactLds, job->transp, job->mirrors, manyCursors,
+                           hitIndex != nullptr || counters != nullptr);
     if (!fn) return fail(GRAFT_ERR_UNSUPPORTED, "this development build holds no kernel for the job");
     if (job->lds && std::find(D->configured.begin(), D->configured.end(), (const void *)fn) == D->configured.end()) {
         // more dynamic LDS than the default limit: raised once per kernel and device, when the kernel is first used
@@ -1114,7 +1136,7 @@ int launchTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int
     // tiles per ticket: 1 for expensive tiles, 2 or 4 for cheap ones, but never so many that a wave gets fewer than 8 draws
     // (load balance at the end of the launch)
     // (with candidate lists a ticket's tiles share one tile list per row of tiles: longer tickets)
-    long long perTicket = manyCursors ? (job->screen >= 6 && !job->mirrors ? 4 : 2) : 1;
+    long long perTicket = samples < 4 ? (job->screen >= 6 && !job->mirrors ? 4 : 2) : 1;
     if (perTicket * waves * 8 > tiles) perTicket = tiles / (waves * 8) < 1 ? 1 : tiles / (waves * 8);
 #ifndef GRAFT_COARSE_TILES
 #define GRAFT_COARSE_TILES 4

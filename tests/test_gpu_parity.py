@@ -38,6 +38,9 @@ def assert_parity(rt, row0=0, n_rows=None):
     assert tests == want["counters"][1] + extra * rt.numShapes
     # the queries really made: all but the shadow rays whose answer a later light of the same hit overwrites
     assert rt.last_rays_traced == want["counters"][0] + extra - want["counters"][3]
+    # the frame alone (no mask, no counts): some jobs run kernels of their own for such launches
+    plain = rt.render_rows(row0, n_rows, GRAFT_OUT_F64_RGB)
+    assert np.array_equal(plain.view(np.uint64), want["rgb"].view(np.uint64)), "the frame asked for alone differs"
     return rgb, idx
 
 

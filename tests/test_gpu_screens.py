@@ -46,6 +46,10 @@ def check_all_levels(rt, levels=(0, 1, 2, 3, 4, 5, 6, 7)):
             assert np.array_equal(idx, want["index"]), "index mask differs at screen level %d" % level
             assert np.array_equal(rgb.view(np.uint64), want["rgb"].view(np.uint64)), \
                 "RGB differs at screen level %d (max abs %g)" % (level, np.nanmax(np.abs(rgb - want["rgb"])))
+            if level >= 6:   # launches that ask for the frame alone run kernels of their own at these levels
+                plain = rt.render_rows(0, None, GRAFT_OUT_F64_RGB)
+                assert np.array_equal(plain.view(np.uint64), want["rgb"].view(np.uint64)), \
+                    "the frame asked for alone differs at screen level %d" % level
     finally:
         set_diagnostic("screen_cap", old)
 
@@ -405,6 +409,17 @@ def test_lists_more_survivors_than_one_round_holds(gpu):
     check_all_levels(rt, levels=(0, 6, 7))
     rt.aliasing, rt.numPasses = ANTIALIASING_ON, 2
     check_all_levels(rt, levels=(0, 6))
+
+
+def test_lists_supersampled_without_a_table_of_scale_factors(gpu):
+    """Supersampled frames whose table of sample scale factors is not in LDS -- more than 8 passes per pixel side -- run
+    the list kernels that work the two getNewPoint steps out per sample (mainTracing.c:405-408)."""
+    rt = matte(scene(66, 100, size=(24, 16), lights=2, radius=(4.0, 25.0)))
+    rt.aliasing, rt.numPasses = ANTIALIASING_ON, 9
+    check_all_levels(rt, levels=(0, 6, 7))
+    rt = scene(67, 100, size=(16, 16), lights=2, radius=(4.0, 25.0), refl=0.5, depth=3)
+    rt.aliasing, rt.numPasses = ANTIALIASING_ON, 10
+    check_all_levels(rt, levels=(0, 7))
 
 
 def test_lists_tile_list_overflow_and_wide_views(gpu):
