@@ -193,7 +193,8 @@ GRAFT_API int graftJobScreenLevel(const GraftJob *job);
  * ADDED to.  Asynchronous on `stream` (a hipStream_t; NULL = the library's stream).  Traces of one job may be
  * queued back to back on one stream; on different streams they must not overlap in time (a job has one set of tile
  * counters).  At most 0x7fff0000 tiles of 8x8 pixels per call.  This is the double loop of mainTracing.c:392-441
- * for those rows. */
+ * for those rows.  (The frame is all that launchRays produces; a call that passes neither `hitIndex` nor `counters`
+ * may run a leaner kernel than one that does -- the frame is the same bit for bit.) */
 GRAFT_API int graftJobTrace(GraftJob *job, int row0, int nRows, int format, void *frame, int32_t *hitIndex,
                             GraftCounters *counters, void *stream);
 

@@ -58,4 +58,5 @@ def test_kernel_stats_file_beside_the_record(path):
     assert abs(sum(durations[-steps:]) / steps - rec["kernel_trace"]["warm_average_ns"]) < 1.0
     with open(sorted(stats)[-1]) as f:
         trace_rows = [r for r in csv.DictReader(f) if "traceKernel" in r["Name"]]
-    assert trace_rows and int(trace_rows[0]["Calls"]) == len(durations)
+    # (a job may run two kernels: the bench's counting launch asks for ray counts, its timed launches for the frame alone)
+    assert trace_rows and sum(int(r["Calls"]) for r in trace_rows) == len(durations)
