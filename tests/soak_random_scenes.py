@@ -35,7 +35,8 @@ for seed in range(first, first + count):
         set_diagnostic("tiles_per_ticket", pick(0, 0, 2, 3, 5, 8))
     rt = ts.scene(1000 + seed, n, size=size, lights=lights, radius=pick((2.0, 9.0), (5.0, 40.0), (20.0, 120.0)),
                   box=pick(150.0, 400.0), refl=pick(0.0, 0.4, 0.9), depth=pick(1, 2, 3, 6),
-                  projection=pick(PERSPECTIVE, PERSPECTIVE, ORTHOGRAPHIC), passes=pick(0, 0, 2, 3))
+                  projection=pick(PERSPECTIVE, PERSPECTIVE, ORTHOGRAPHIC),
+                  passes=pick(0, 0, 2, 3, 9) if n <= 90 and not wide else pick(0, 0, 2, 3))  # (9: no table of scale factors)
     k = rt.numShapes
     if pick(0, 1):  # two planes
         rt.planeSetup([0.0, 1.0, 0.0], [0.0, -300.0, 0.0], k, [.6, .6, .7], pick(0.0, 0.3), 0.1, 1.0, 0.0)
