@@ -228,8 +228,10 @@ __device__ __forceinline__ double hitDistance(double t, double sx, double sy, do
 }
 
 // sphereIntersect (shapes.c:47-73) for sphere `shape` + the closest-hit update described above.
+// `fresh` (the same for all lanes): no lane has a candidate yet, so a hit is the lane's best without any comparison.
 __device__ __forceinline__ void exactSphereLazy(const double4v c4, int shape, double sx, double sy, double sz, double dx,
-                                                double dy, double dz, double slackBase, double slackScale, Best &best) {
+                                                double dy, double dz, double slackBase, double slackScale, Best &best,
+                                                bool fresh = false) {
     const double vx = sx - c4.x, vy = sy - c4.y, vz = sz - c4.z;
     const double b = vx * dx + vy * dy + vz * dz;
     const double vv = vx * vx + vy * vy + vz * vz;
@@ -249,6 +251,13 @@ __device__ __forceinline__ void exactSphereLazy(const double4v c4, int shape, do
         t = tNear >= 0 ? tNear : tFar;
     }
     const bool hit = !(t < 0);  // (true for NaN, as in the reference: shapes.c:66 only rejects t < 0)
+#ifndef GRAFT_NO_FRESH_ROUND  // (A/B builds)
+    if (fresh) {
+        best.t = hit ? t : best.t;
+        best.shape = hit ? shape : best.shape;
+        return;
+    }
+#endif
     const double slackNew = slackScale * (t + slackBase), slackBest = slackScale * (best.t + slackBase);
     const bool first = best.shape < 0;
     const bool closer = hit && (first || t + slackNew < best.t - slackBest);
@@ -1098,6 +1107,7 @@ __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx,
     if constexpr (!GLOBAL) {
         // numbers + 1 of the spheres that passed the screen and wait for the exact test, 16 bits each, the latest lowest
         unsigned long long kept = pending >= 0 ? (unsigned long long)(pending + 1) : 0;
+        bool fresh = true;  // no exact test has run yet for this ray (the same for all lanes: the first trip of the exact loop)
         for (;;) {
             bool screening = (__ballot(len > 0) != 0) & (__ballot((unsigned)(kept >> 32) > 0xffffu) == 0);
             while (screening) {
@@ -1122,8 +1132,9 @@ __device__ __forceinline__ void closestHitLists(const TraceParams &P, double sx,
                 if (kept != 0) {
                     const int k = (int)(kept & 0xffffu) - 1;
                     kept >>= 16;
-                    exactSphereLazy(geom[k], k, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest);
+                    exactSphereLazy(geom[k], k, sx, sy, sz, dx, dy, dz, slackBase, slackScale, closest, fresh);
                 }
+                fresh = false;
                 testing = __ballot(kept != 0) != 0;
             }
             if (__ballot(len > 0) == 0) break;
